@@ -1,0 +1,170 @@
+/* mipt -- MI355X path-tracing core behind timstr/pathtracer's scene and render API.
+ *
+ * C ABI of libmipt.so (pathtracer_amd/lib/libmipt.so).  The reference has no FFI of its own: its
+ * boundary is the public C++ API (Scene, Object, Camera, RenderSettings, Renderer, tone mappers).
+ * Each entry point below names the reference interface it stands in for (file:line relative to
+ * the reference checkout); the C++ classes of include/pathtracer/ call these and nothing else.
+ *
+ * All functions return MIPT_OK (0) or a negative mipt_status; nothing throws across this boundary.
+ * Host pointers unless a parameter is marked `device`.  One mipt_ctx drives one GPU; a process that
+ * drives several GPUs creates one ctx per device (or runs one process per GPU).
+ */
+#ifndef MIPT_H
+#define MIPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MIPT_OK = 0,
+    MIPT_ERR_ARGUMENT = -1,     /* null pointer, zero size, unknown kind, W or H < 2 */
+    MIPT_ERR_NO_DEVICE = -2,    /* no usable HIP device / HIP runtime failure at init */
+    MIPT_ERR_HIP = -3,          /* a HIP call failed; mipt_last_hip_error() has the code */
+    MIPT_ERR_NOT_INVERTIBLE = -4, /* determinant < 1e-6: the reference's Linear::inverse refuses it */
+    MIPT_ERR_CANCELLED = -5,    /* mipt_cancel() arrived during the call; outputs hold what was finished */
+    MIPT_ERR_TOO_LARGE = -6,    /* size beyond a documented limit */
+    MIPT_ERR_OUT_OF_MEMORY = -7
+} mipt_status;
+
+typedef struct mipt_ctx mipt_ctx;
+typedef struct mipt_scene mipt_scene;
+
+/* Primitive kinds: the concrete Object subclasses (include/Object.hpp:60-102) and the demo's
+ * CraterBallObject (PathTracerDemo.cpp:352-483). */
+enum { MIPT_SPHERE = 0, MIPT_BOX = 1, MIPT_TRIANGLE = 2, MIPT_CRATERBALL = 3 };
+
+/* What Scene::updateGeometry (src/Scene.cpp:80-87) flattens its objects into.  Arrays are copied
+ * by mipt_scene_upload; the caller keeps ownership.
+ *   fwd / inv   Object::m_transformation / m_inverseTransformation (include/Object.hpp:55-56):
+ *               12 floats each, Linear row-major (m[3*r+c]) then the translation.  inv must be what
+ *               Object::setTransformation caches (mipt_affine_inverse computes exactly that).
+ *   params      9 floats per primitive: sphere {radius}; box {half x,y,z}; triangle {a, b, c};
+ *               crater ball {offset x,y,z}
+ *   materials   14 floats per row in BasicMaterial's member order (include/BasicMaterial.hpp:32-39):
+ *               diffuse, specular, sharpness, reflected absorption rgb, emitted luminance rgb,
+ *               transmittance, index of refraction, internal absorption rgb
+ *   noise_transform  the demo's noiseTransform() (PathTracerDemo.cpp:37-54), 12 floats; may be NULL
+ *               when the scene holds no SDF primitive */
+typedef struct {
+    uint32_t n_prims;
+    const uint32_t* kind;
+    const float* fwd;
+    const float* inv;
+    const float* params;
+    const uint32_t* material;
+    uint32_t n_materials;
+    const float* materials;
+    const float* noise_transform;
+} mipt_scene_desc;
+
+/* Camera (include/Camera.hpp:25-30): m_transform, aspect ratio, field of view in degrees (used as a
+ * half angle, src/Camera.cpp:76), focal distance, focal blur radius. */
+typedef struct {
+    float transform[12];
+    float aspect;
+    float fov_degrees;
+    float focal_distance;
+    float blur_radius;
+} mipt_camera;
+
+enum {
+    MIPT_FLAG_NO_JITTER = 1u    /* pixel-centre samples: sx = x/(W-1), sy = y/(H-1) (parity maps) */
+};
+
+/* RenderSettings (include/RenderSettings.hpp:18-22) plus what the reference keeps implicit:
+ * the random seed and, for sample sharding across GPUs, which global sample indices to draw. */
+typedef struct {
+    uint32_t width;
+    uint32_t height;
+    uint32_t bounces;        /* RenderSettings::numBounces: ray casts per path (src/Scene.cpp:21) */
+    uint32_t spp;            /* samples this call draws per pixel */
+    uint64_t seed;
+    uint32_t first_sample;   /* global index of this call's first sample (0 on one GPU) */
+    uint32_t flags;
+} mipt_settings;
+
+typedef struct {
+    uint64_t paths;          /* (pixel, sample) pairs started */
+    uint64_t rays;           /* closest-hit queries (Tree::hit equivalents) */
+    uint64_t sdf_rays;       /* rays that entered an SDF primitive's bounding box */
+    uint64_t sdf_shades;     /* hits shaded on an SDF primitive (4 SDF evaluations each) */
+    double   ms_device;      /* stream time of the call, HIP events */
+} mipt_stats;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* Renderer::Renderer / startThreadPool (src/Renderer.cpp:9-35): binds a GPU instead of starting
+ * CPU workers.  device < 0 uses the current HIP device.  stream is a hipStream_t to launch on, or
+ * NULL for a stream the context creates. */
+int  mipt_init(int device, void* stream, mipt_ctx** out);
+/* Renderer::~Renderer / stopThreadPool (src/Renderer.cpp:14-16, 37-52). */
+void mipt_shutdown(mipt_ctx*);
+/* Renderer::cancelRender (src/Renderer.cpp:174-176): callable from any thread, lock-free.  The
+ * running render call stops at the next sample batch and returns MIPT_ERR_CANCELLED. */
+int  mipt_cancel(mipt_ctx*);
+int  mipt_last_hip_error(const mipt_ctx*);
+const char* mipt_strerror(int status);
+
+/* ---- scene -------------------------------------------------------------------------------- */
+/* Scene::updateGeometry (src/Scene.cpp:80-87) + ObjectTree::Tree::Tree (src/ObjectTree.cpp:80-83):
+ * packs primitives and materials into HBM and builds the linear BVH (a scalable builder replaces
+ * makeTree, src/ObjectTree.cpp:90-184; any topology returns the same closest hit because the
+ * reference's tree never culls). */
+int  mipt_scene_upload(mipt_ctx*, const mipt_scene_desc*, mipt_scene** out);
+void mipt_scene_free(mipt_scene*);
+/* BVH facts for tests and reports: out4 = node count, depth, analytic primitives, SDF primitives. */
+int  mipt_scene_info(const mipt_scene*, uint32_t out4[4]);
+
+/* ---- rendering ---------------------------------------------------------------------------- */
+/* Renderer::render (src/Renderer.cpp:139-172): one frame of settings->spp samples per pixel;
+ * out_rgb (host, width*height*3 floats, row-major like Image, src/Image.cpp:83-87) receives the
+ * per-pixel mean. */
+int  mipt_render(mipt_ctx*, const mipt_scene*, const mipt_camera*, const mipt_settings*,
+                 float* out_rgb, mipt_stats* stats /* nullable */);
+/* The same samples ADDED, unnormalised, into a device buffer (width*height*3 floats): the per-GPU
+ * radiance sum of a sample-sharded render.  The caller zeroes the buffer, all-reduces it across
+ * ranks and scales by 1/total_spp (mipt_scale_device).  Work is queued on the context's stream;
+ * the call returns after the stream has drained. */
+int  mipt_render_accumulate(mipt_ctx*, const mipt_scene*, const mipt_camera*, const mipt_settings*,
+                            float* device_sum, mipt_stats* stats /* nullable */);
+/* device_out[i] = device_in[i] * k  (the `acc * sppInv` of src/Renderer.cpp:102-105); in-place allowed. */
+int  mipt_scale_device(mipt_ctx*, const float* device_in, float k, size_t n_floats, float* device_out);
+
+/* Parity probes (no counterpart in the reference's API; they expose stages of the hot path).
+ * Pixel-centre primary rays through Camera::getViewRay and the closest hit of each:
+ * out_prim = primitive index or -1, out_t = (hit - ray.pos) . ray.dir (src/ObjectTree.cpp:43-44). */
+int  mipt_primary_hits(mipt_ctx*, const mipt_scene*, const mipt_camera*, uint32_t width, uint32_t height,
+                       int32_t* out_prim, float* out_t);
+/* Scene::trace (src/Scene.cpp:18-78) for n explicit rays; ray i draws from the random stream of
+ * path (pixel = i, sample = 0).  out_first_prim / out_first_t (nullable) report the first hit. */
+int  mipt_trace_rays(mipt_ctx*, const mipt_scene*, uint32_t n, const float* ray_pos3, const float* ray_dir3,
+                     uint32_t bounces, uint64_t seed, float* out_rgb, int32_t* out_first_prim, float* out_first_t);
+
+/* ---- tone mapping ------------------------------------------------------------------------- */
+/* ReinhardToneMapper / FilmicToneMapper::operator() (src/ToneMapper.cpp:6-72): kind 0 Reinhard,
+ * 1 filmic.  Host image in, host image out. */
+int  mipt_tonemap(mipt_ctx*, int kind, const float* in_rgb, float* out_rgb, size_t width, size_t height);
+/* The same on device buffers (after the all-reduce of a sharded render); in-place allowed. */
+int  mipt_tonemap_device(mipt_ctx*, int kind, const float* device_in, float* device_out, size_t width, size_t height);
+
+/* ---- host-side helpers (no GPU needed) ------------------------------------------------------ */
+/* Affine::inverse as Object::setTransformation applies it (src/LinearAlgebra.cpp:207-264,
+ * src/Object.cpp:15-20), for n transforms.  Returns MIPT_ERR_NOT_INVERTIBLE if any determinant is
+ * below 1e-6 (the reference asserts). */
+int  mipt_affine_inverse(size_t n, const float* fwd12, float* inv12);
+/* Linear::RotationX/Y/Z (src/LinearAlgebra.cpp:90-118); axis 'x', 'y' or 'z'; 9 floats each. */
+int  mipt_rotation(char axis, size_t n, const float* angles, float* out9);
+/* Affine * Affine (src/LinearAlgebra.cpp:413-415), elementwise over n pairs. */
+int  mipt_affine_mul(size_t n, const float* a12, const float* b12, float* out12);
+/* Translation(t) * RotationX(r[0]) * RotationY(r[1]) * RotationZ(r[2]) (PathTracerDemo.cpp:48-51). */
+int  mipt_noise_transform(const float t3[3], const float r3[3], float out12[12]);
+/* Object::getBoundingBox (src/Object.cpp:46-80): out6 = min xyz, max xyz of the padded world box. */
+int  mipt_world_bounds(uint32_t kind, const float fwd12[12], const float params9[9], float out6[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPT_H */

@@ -1,0 +1,597 @@
+// C ABI of libmipt.so (include/mipt.h): context, scene upload, the per-frame wavefront loop, tone
+// mapping and the host-side affine helpers.
+#include "../../include/mipt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "bvh.h"
+#include "device_types.h"
+#include "hostmath.h"
+#include "kernels.h"
+
+using namespace mipt;
+
+struct mipt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::atomic<int> cancel{0};
+    int last_hip = 0;
+    std::mutex mutex;   // render calls are serialised, as Renderer::render is (src/Renderer.cpp:144)
+
+    // working set, grown on demand and kept between calls
+    size_t slots_cap = 0;
+    PathBuffers pb{};
+    void* arena = nullptr;
+    float* frame = nullptr;          // per-call radiance sum (mipt_render)
+    size_t frame_cap = 0;
+    float* tm_scratch = nullptr;     // Reinhard partials
+    float* stage = nullptr;          // staging for probes / host tone mapping
+    size_t stage_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct mipt_scene {
+    mipt_ctx* ctx = nullptr;
+    SceneDev dev{};
+    void* d_prims = nullptr;
+    void* d_tri = nullptr;
+    void* d_mats = nullptr;
+    void* d_nodes = nullptr;
+    void* d_sdf = nullptr;
+    uint32_t n_nodes = 0, n_analytic = 0, n_sdf = 0;
+    int depth = 0;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                         \
+    do {                                           \
+        const hipError_t e_ = (expr);              \
+        if (e_ != hipSuccess) {                    \
+            (ctx)->last_hip = static_cast<int>(e_);\
+            return MIPT_ERR_HIP;                   \
+        }                                          \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t batch_path_budget() {
+    // paths in flight per sample batch; the per-slot state is 96 bytes plus 16 bytes of queues
+    size_t budget = size_t(32) << 20;
+    if (const char* e = std::getenv("MIPT_BATCH_PATHS")) {
+        const long long v = std::atoll(e);
+        if (v > 0) budget = static_cast<size_t>(v);
+    }
+    return budget;
+}
+
+int ensure_slots(mipt_ctx* c, size_t slots) {
+    if (slots <= c->slots_cap) return MIPT_OK;
+    if (c->arena) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(c->arena));
+        c->arena = nullptr;
+        c->slots_cap = 0;
+    }
+    const size_t n = align_up(slots, 256);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    const size_t o_ro = take(n * 16), o_rd = take(n * 16), o_att = take(n * 16), o_rad = take(n * 16);
+    const size_t o_key = take(n * 8), o_pos = take(n * 16);
+    const size_t o_q0 = take(n * 4), o_q1 = take(n * 4), o_qs = take(n * 4), o_qss = take(n * 4);
+    const size_t o_cnt = take(sizeof(BounceCounters) * (kMaxBounces + 1));
+    const size_t o_tot = take(sizeof(Totals));
+    void* base = nullptr;
+    const hipError_t e = hipMalloc(&base, off);
+    if (e != hipSuccess) {
+        c->last_hip = static_cast<int>(e);
+        return e == hipErrorOutOfMemory ? MIPT_ERR_OUT_OF_MEMORY : MIPT_ERR_HIP;
+    }
+    char* b = static_cast<char*>(base);
+    c->arena = base;
+    c->slots_cap = n;
+    c->pb.ray_o = reinterpret_cast<float4*>(b + o_ro);
+    c->pb.ray_d = reinterpret_cast<float4*>(b + o_rd);
+    c->pb.att = reinterpret_cast<float4*>(b + o_att);
+    c->pb.rad = reinterpret_cast<float4*>(b + o_rad);
+    c->pb.hit_key = reinterpret_cast<unsigned long long*>(b + o_key);
+    c->pb.hit_pos = reinterpret_cast<float4*>(b + o_pos);
+    c->pb.queue[0] = reinterpret_cast<uint32_t*>(b + o_q0);
+    c->pb.queue[1] = reinterpret_cast<uint32_t*>(b + o_q1);
+    c->pb.sdf_queue = reinterpret_cast<uint32_t*>(b + o_qs);
+    c->pb.sdf_shade_queue = reinterpret_cast<uint32_t*>(b + o_qss);
+    c->pb.counters = reinterpret_cast<BounceCounters*>(b + o_cnt);
+    c->pb.totals = reinterpret_cast<Totals*>(b + o_tot);
+    return MIPT_OK;
+}
+
+int ensure_floats(mipt_ctx* c, float** buf, size_t* cap, size_t n) {
+    if (n <= *cap) return MIPT_OK;
+    if (*buf) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(*buf));
+        *buf = nullptr;
+        *cap = 0;
+    }
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(buf), n * sizeof(float));
+    if (e != hipSuccess) {
+        c->last_hip = static_cast<int>(e);
+        return e == hipErrorOutOfMemory ? MIPT_ERR_OUT_OF_MEMORY : MIPT_ERR_HIP;
+    }
+    *cap = n;
+    return MIPT_OK;
+}
+
+CameraRec pack_camera(const mipt_camera& cam) {
+    CameraRec r;
+    std::memcpy(r.lin, cam.transform, sizeof(float) * 9);
+    std::memcpy(r.tr, cam.transform + 9, sizeof(float) * 3);
+    r.aspect = cam.aspect;
+    // the per-ray constants of Camera::getViewRay (src/Camera.cpp:72-77), hoisted with the same float ops
+    r.fov_scale = std::tan(cam.fov_degrees * 3.141592654f / 180.0f);
+    r.inv_focal = 1.0f / cam.focal_distance;
+    r.blur_rad = cam.blur_radius * std::max(cam.aspect, 1.0f / cam.aspect);
+    return r;
+}
+
+// One sample batch: generate (or preloaded rays) -> bounce loop.  Leaves per-path radiance in pb.rad.
+void enqueue_bounces(mipt_ctx* c, const mipt_scene* sc, const BatchParams& bp, uint32_t bounces) {
+    for (uint32_t b = 0; b < bounces; ++b) {
+        launch_extend(c->stream, sc->dev, bp, c->pb, b, sc->depth);
+        if (sc->n_sdf) launch_sdf_march(c->stream, sc->dev, bp, c->pb, b);
+        launch_shade(c->stream, sc->dev, bp, c->pb, b, bounces);
+        if (sc->n_sdf) launch_shade_sdf(c->stream, sc->dev, bp, c->pb, b, bounces);
+    }
+    launch_finish_batch(c->stream, c->pb, bounces, bp.n_slots);
+}
+
+int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const mipt_settings* st, float* d_sum, mipt_stats* stats) {
+    if (!c || !sc || !cam || !st || !d_sum) return MIPT_ERR_ARGUMENT;
+    if (st->width < 2 || st->height < 2 || st->spp == 0 || st->bounces == 0) return MIPT_ERR_ARGUMENT;
+    if (st->bounces > static_cast<uint32_t>(kMaxBounces)) return MIPT_ERR_TOO_LARGE;
+    const size_t n_pix = static_cast<size_t>(st->width) * st->height;
+    if (n_pix > (size_t(1) << 31)) return MIPT_ERR_TOO_LARGE;
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->cancel.store(0);
+    const size_t budget = batch_path_budget();
+    uint32_t per_batch = static_cast<uint32_t>(std::max<size_t>(1, budget / n_pix));
+    per_batch = std::min(per_batch, st->spp);
+    if (n_pix * per_batch > (size_t(1) << 31)) return MIPT_ERR_TOO_LARGE;
+    int rc = ensure_slots(c, n_pix * per_batch);
+    if (rc != MIPT_OK) return rc;
+    const CameraRec cr = pack_camera(*cam);
+    HIP_TRY(c, hipMemsetAsync(c->pb.totals, 0, sizeof(Totals), c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    uint32_t done = 0;
+    int status = MIPT_OK;
+    while (done < st->spp) {
+        if (c->cancel.load(std::memory_order_relaxed)) {
+            status = MIPT_ERR_CANCELLED;
+            break;
+        }
+        const uint32_t now = std::min(per_batch, st->spp - done);
+        BatchParams bp;
+        bp.n_pix = static_cast<uint32_t>(n_pix);
+        bp.n_slots = static_cast<uint32_t>(n_pix * now);
+        bp.width = st->width;
+        bp.height = st->height;
+        bp.first_sample = st->first_sample + done;
+        bp.flags = st->flags;
+        bp.seed = st->seed;
+        HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
+        launch_generate(c->stream, cr, bp, c->pb);
+        enqueue_bounces(c, sc, bp, st->bounces);
+        launch_accumulate(c->stream, bp, c->pb, d_sum);
+        done += now;
+        // keep at most a couple of batches queued so that cancellation stays responsive
+        if (done < st->spp) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    if (stats) {
+        Totals t{};
+        HIP_TRY(c, hipMemcpy(&t, c->pb.totals, sizeof(t), hipMemcpyDeviceToHost));
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        stats->paths = static_cast<uint64_t>(n_pix) * done;
+        stats->rays = t.rays;
+        stats->sdf_rays = t.sdf_rays;
+        stats->sdf_shades = t.sdf_shades;
+        stats->ms_device = ms;
+    }
+    return status;
+}
+
+}   // namespace
+
+extern "C" {
+
+int mipt_init(int device, void* stream, mipt_ctx** out) {
+    if (!out) return MIPT_ERR_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return MIPT_ERR_NO_DEVICE;
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) return MIPT_ERR_NO_DEVICE;
+    }
+    if (device >= count) return MIPT_ERR_ARGUMENT;
+    if (hipSetDevice(device) != hipSuccess) return MIPT_ERR_NO_DEVICE;
+    auto* c = new (std::nothrow) mipt_ctx;
+    if (!c) return MIPT_ERR_OUT_OF_MEMORY;
+    c->device = device;
+    if (stream) {
+        c->stream = static_cast<hipStream_t>(stream);
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return MIPT_ERR_NO_DEVICE;
+        }
+        c->own_stream = true;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->tm_scratch), reinhard_scratch_floats() * sizeof(float)) != hipSuccess) {
+        mipt_shutdown(c);
+        return MIPT_ERR_NO_DEVICE;
+    }
+    *out = c;
+    return MIPT_OK;
+}
+
+void mipt_shutdown(mipt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->frame) (void)hipFree(c->frame);
+    if (c->stage) (void)hipFree(c->stage);
+    if (c->tm_scratch) (void)hipFree(c->tm_scratch);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mipt_cancel(mipt_ctx* c) {
+    if (!c) return MIPT_ERR_ARGUMENT;
+    c->cancel.store(1, std::memory_order_relaxed);
+    return MIPT_OK;
+}
+
+int mipt_last_hip_error(const mipt_ctx* c) { return c ? c->last_hip : 0; }
+
+const char* mipt_strerror(int s) {
+    switch (s) {
+        case MIPT_OK: return "ok";
+        case MIPT_ERR_ARGUMENT: return "invalid argument";
+        case MIPT_ERR_NO_DEVICE: return "no usable HIP device";
+        case MIPT_ERR_HIP: return "HIP call failed";
+        case MIPT_ERR_NOT_INVERTIBLE: return "transformation determinant below 1e-6";
+        case MIPT_ERR_CANCELLED: return "render cancelled";
+        case MIPT_ERR_TOO_LARGE: return "size beyond the supported limit";
+        case MIPT_ERR_OUT_OF_MEMORY: return "out of memory";
+    }
+    return "unknown status";
+}
+
+int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
+    if (!c || !d || !out) return MIPT_ERR_ARGUMENT;
+    *out = nullptr;
+    if (d->n_prims == 0 || !d->kind || !d->fwd || !d->inv || !d->params || !d->material || !d->materials || d->n_materials == 0)
+        return MIPT_ERR_ARGUMENT;
+    if (d->n_prims > (1u << 30)) return MIPT_ERR_TOO_LARGE;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t n = d->n_prims;
+    std::vector<PrimRec> prims(n);
+    std::vector<float> tri_c;
+    std::vector<BuildBox> boxes;
+    std::vector<SdfBox> sdf;
+    boxes.reserve(n);
+    bool any_tri = false, any_sdf = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t k = d->kind[i];
+        if (k > MIPT_CRATERBALL || d->material[i] >= d->n_materials) return MIPT_ERR_ARGUMENT;
+        any_tri |= (k == MIPT_TRIANGLE);
+        any_sdf |= (k == MIPT_CRATERBALL);
+    }
+    if (any_sdf && !d->noise_transform) return MIPT_ERR_ARGUMENT;
+    if (any_tri) tri_c.assign(static_cast<size_t>(3) * n, 0.0f);
+    for (uint32_t i = 0; i < n; ++i) {
+        PrimRec& r = prims[i];
+        std::memcpy(r.inv, d->inv + 12 * static_cast<size_t>(i), sizeof(r.inv));
+        std::memcpy(r.fwd, d->fwd + 12 * static_cast<size_t>(i), sizeof(r.fwd));
+        const float* p = d->params + 9 * static_cast<size_t>(i);
+        std::memcpy(r.p, p, sizeof(r.p));
+        r.kind = d->kind[i];
+        r.material = d->material[i];
+        if (r.kind == MIPT_TRIANGLE) std::memcpy(&tri_c[3 * static_cast<size_t>(i)], p + 6, sizeof(float) * 3);
+        float lo[3], hi[3];
+        if (!world_bounds(r.kind, r.fwd, p, lo, hi)) return MIPT_ERR_ARGUMENT;
+        // The reference's hits lie inside its padded boxes (1e-3 in local units); widen a little more
+        // so that rounding in the hit position or in the slab test can never cull a hit it would find.
+        for (int a = 0; a < 3; ++a) {
+            const float m = std::max(std::fabs(lo[a]), std::fabs(hi[a]));
+            const float pad = 1e-5f * m + 1e-6f;
+            lo[a] -= pad;
+            hi[a] += pad;
+        }
+        if (r.kind == MIPT_CRATERBALL) {
+            SdfBox s{};
+            std::memcpy(s.lo, lo, sizeof(lo));
+            std::memcpy(s.hi, hi, sizeof(hi));
+            s.prim = i;
+            sdf.push_back(s);
+        } else {
+            BuildBox b;
+            std::memcpy(b.lo, lo, sizeof(lo));
+            std::memcpy(b.hi, hi, sizeof(hi));
+            b.prim = i;
+            boxes.push_back(b);
+        }
+    }
+    std::vector<MaterialRec> mats(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const float* m = d->materials + 14 * static_cast<size_t>(i);
+        MaterialRec& r = mats[i];
+        r.diffuse = m[0];
+        r.specular = m[1];
+        r.sharpness = m[2];
+        std::memcpy(r.albedo, m + 3, 12);
+        std::memcpy(r.emitted, m + 6, 12);
+        r.transmittance = m[9];
+        r.ior = m[10];
+        std::memcpy(r.internal, m + 11, 12);
+        r.pad[0] = r.pad[1] = 0.0f;
+    }
+    const uint32_t n_analytic = static_cast<uint32_t>(boxes.size());
+    BvhResult bvh = build_bvh(std::move(boxes));
+
+    auto* s = new (std::nothrow) mipt_scene;
+    if (!s) return MIPT_ERR_OUT_OF_MEMORY;
+    s->ctx = c;
+    auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+        if (bytes == 0) return hipSuccess;
+        hipError_t e = hipMalloc(dst, bytes);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    hipError_t e = upload(&s->d_prims, prims.data(), prims.size() * sizeof(PrimRec));
+    if (e == hipSuccess) e = upload(&s->d_tri, tri_c.data(), tri_c.size() * sizeof(float));
+    if (e == hipSuccess) e = upload(&s->d_mats, mats.data(), mats.size() * sizeof(MaterialRec));
+    if (e == hipSuccess) e = upload(&s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode));
+    if (e == hipSuccess) e = upload(&s->d_sdf, sdf.data(), sdf.size() * sizeof(SdfBox));
+    if (e != hipSuccess) {
+        c->last_hip = static_cast<int>(e);
+        mipt_scene_free(s);
+        return e == hipErrorOutOfMemory ? MIPT_ERR_OUT_OF_MEMORY : MIPT_ERR_HIP;
+    }
+    s->dev.prims = static_cast<const PrimRec*>(s->d_prims);
+    s->dev.tri_c = static_cast<const float*>(s->d_tri);
+    s->dev.materials = static_cast<const MaterialRec*>(s->d_mats);
+    s->dev.nodes = static_cast<const BvhNode*>(s->d_nodes);
+    s->dev.sdf_boxes = static_cast<const SdfBox*>(s->d_sdf);
+    s->dev.n_sdf = static_cast<uint32_t>(sdf.size());
+    s->dev.n_prims = n;
+    if (d->noise_transform) std::memcpy(s->dev.noise, d->noise_transform, sizeof(float) * 12);
+    else std::memset(s->dev.noise, 0, sizeof(s->dev.noise));
+    s->n_nodes = static_cast<uint32_t>(bvh.nodes.size());
+    s->n_analytic = n_analytic;
+    s->n_sdf = static_cast<uint32_t>(sdf.size());
+    s->depth = bvh.depth;
+    *out = s;
+    return MIPT_OK;
+}
+
+void mipt_scene_free(mipt_scene* s) {
+    if (!s) return;
+    if (s->ctx) {
+        (void)hipSetDevice(s->ctx->device);
+        (void)hipStreamSynchronize(s->ctx->stream);
+    }
+    for (void* p : {s->d_prims, s->d_tri, s->d_mats, s->d_nodes, s->d_sdf})
+        if (p) (void)hipFree(p);
+    delete s;
+}
+
+int mipt_scene_info(const mipt_scene* s, uint32_t out4[4]) {
+    if (!s || !out4) return MIPT_ERR_ARGUMENT;
+    out4[0] = s->n_nodes;
+    out4[1] = static_cast<uint32_t>(s->depth);
+    out4[2] = s->n_analytic;
+    out4[3] = s->n_sdf;
+    return MIPT_OK;
+}
+
+int mipt_render_accumulate(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const mipt_settings* st, float* device_sum, mipt_stats* stats) {
+    if (!c) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    return render_into(c, sc, cam, st, device_sum, stats);
+}
+
+int mipt_render(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const mipt_settings* st, float* out_rgb, mipt_stats* stats) {
+    if (!c || !st || !out_rgb) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    const size_t n = static_cast<size_t>(st->width) * st->height * 3;
+    if (n == 0) return MIPT_ERR_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_floats(c, &c->frame, &c->frame_cap, n);
+    if (rc != MIPT_OK) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->frame, 0, n * sizeof(float), c->stream));   // Image starts black (src/Image.cpp:8-13)
+    rc = render_into(c, sc, cam, st, c->frame, stats);
+    if (rc != MIPT_OK && rc != MIPT_ERR_CANCELLED) return rc;
+    launch_scale(c->stream, c->frame, 1.0f / static_cast<float>(st->spp), n, c->frame);   // acc * sppInv
+    HIP_TRY(c, hipMemcpyAsync(out_rgb, c->frame, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return rc;
+}
+
+int mipt_scale_device(mipt_ctx* c, const float* in, float k, size_t n, float* out) {
+    if (!c || !in || !out) return MIPT_ERR_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    launch_scale(c->stream, in, k, n, out);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MIPT_OK;
+}
+
+int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, uint32_t width, uint32_t height, int32_t* out_prim, float* out_t) {
+    if (!c || !sc || !cam || !out_prim || !out_t || width < 2 || height < 2) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = static_cast<size_t>(width) * height;
+    if (n > (size_t(1) << 28)) return MIPT_ERR_TOO_LARGE;
+    int rc = ensure_slots(c, n);
+    if (rc != MIPT_OK) return rc;
+    BatchParams bp{};
+    bp.n_pix = bp.n_slots = static_cast<uint32_t>(n);
+    bp.width = width;
+    bp.height = height;
+    bp.flags = MIPT_FLAG_NO_JITTER;
+    mipt_camera c0 = *cam;
+    c0.blur_radius = 0.0f;
+    HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
+    launch_generate(c->stream, pack_camera(c0), bp, c->pb);
+    launch_extend(c->stream, sc->dev, bp, c->pb, 0, sc->depth);
+    if (sc->n_sdf) launch_sdf_march(c->stream, sc->dev, bp, c->pb, 0);
+    std::vector<unsigned long long> keys(n);
+    HIP_TRY(c, hipMemcpyAsync(keys.data(), c->pb.hit_key, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    for (size_t i = 0; i < n; ++i) {
+        if (keys[i] == ~0ull) {
+            out_prim[i] = -1;
+            out_t[i] = 0.0f;
+            continue;
+        }
+        const uint32_t ob = static_cast<uint32_t>(keys[i] >> 32);
+        const uint32_t fb = (ob & 0x80000000u) ? (ob ^ 0x80000000u) : ~ob;
+        out_prim[i] = static_cast<int32_t>(keys[i] & 0xffffffffu);
+        std::memcpy(&out_t[i], &fb, 4);
+    }
+    return MIPT_OK;
+}
+
+int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* pos, const float* dir, uint32_t bounces, uint64_t seed,
+                    float* out_rgb, int32_t* out_first_prim, float* out_first_t) {
+    if (!c || !sc || !pos || !dir || !out_rgb || n == 0 || bounces == 0) return MIPT_ERR_ARGUMENT;
+    if (bounces > static_cast<uint32_t>(kMaxBounces) || n > (1u << 28)) return MIPT_ERR_TOO_LARGE;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_slots(c, n);
+    if (rc != MIPT_OK) return rc;
+    rc = ensure_floats(c, &c->stage, &c->stage_cap, static_cast<size_t>(n) * 6);
+    if (rc != MIPT_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->stage, pos, static_cast<size_t>(n) * 12, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->stage + static_cast<size_t>(n) * 3, dir, static_cast<size_t>(n) * 12, hipMemcpyHostToDevice, c->stream));
+    BatchParams bp{};
+    bp.n_pix = bp.n_slots = n;
+    bp.width = n;
+    bp.height = 1;
+    bp.seed = seed;
+    HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
+    launch_load_rays(c->stream, c->stage, c->stage + static_cast<size_t>(n) * 3, n, c->pb);
+    std::vector<unsigned long long> keys;
+    if (out_first_prim || out_first_t) {
+        // first closest hit, before shading overwrites the rays
+        launch_extend(c->stream, sc->dev, bp, c->pb, 0, sc->depth);
+        if (sc->n_sdf) launch_sdf_march(c->stream, sc->dev, bp, c->pb, 0);
+        keys.resize(n);
+        HIP_TRY(c, hipMemcpyAsync(keys.data(), c->pb.hit_key, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
+    }
+    enqueue_bounces(c, sc, bp, bounces);
+    launch_export_rad(c->stream, c->pb, n, c->stage);
+    HIP_TRY(c, hipMemcpyAsync(out_rgb, c->stage, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    for (size_t i = 0; i < keys.size(); ++i) {
+        const bool miss = keys[i] == ~0ull;
+        const uint32_t ob = static_cast<uint32_t>(keys[i] >> 32);
+        const uint32_t fb = (ob & 0x80000000u) ? (ob ^ 0x80000000u) : ~ob;
+        if (out_first_prim) out_first_prim[i] = miss ? -1 : static_cast<int32_t>(keys[i] & 0xffffffffu);
+        if (out_first_t) {
+            if (miss) out_first_t[i] = 0.0f;
+            else std::memcpy(&out_first_t[i], &fb, 4);
+        }
+    }
+    return MIPT_OK;
+}
+
+int mipt_tonemap_device(mipt_ctx* c, int kind, const float* in, float* out, size_t width, size_t height) {
+    if (!c || !in || !out || width == 0 || height == 0 || (kind != 0 && kind != 1)) return MIPT_ERR_ARGUMENT;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (kind == 1) launch_tonemap_filmic(c->stream, in, out, width * height * 3);
+    else launch_tonemap_reinhard(c->stream, in, out, width, height, c->tm_scratch, reinhard_scratch_floats());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return MIPT_OK;
+}
+
+int mipt_tonemap(mipt_ctx* c, int kind, const float* in, float* out, size_t width, size_t height) {
+    if (!c || !in || !out || width == 0 || height == 0 || (kind != 0 && kind != 1)) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = width * height * 3;
+    int rc = ensure_floats(c, &c->stage, &c->stage_cap, n);
+    if (rc != MIPT_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->stage, in, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    rc = mipt_tonemap_device(c, kind, c->stage, c->stage, width, height);
+    if (rc != MIPT_OK) return rc;
+    HIP_TRY(c, hipMemcpy(out, c->stage, n * sizeof(float), hipMemcpyDeviceToHost));
+    return MIPT_OK;
+}
+
+int mipt_affine_inverse(size_t n, const float* fwd, float* inv) {
+    if (!fwd || !inv) return MIPT_ERR_ARGUMENT;
+    for (size_t i = 0; i < n; ++i)
+        if (!affine_inverse(fwd + 12 * i, inv + 12 * i)) return MIPT_ERR_NOT_INVERTIBLE;
+    return MIPT_OK;
+}
+
+int mipt_rotation(char axis, size_t n, const float* angles, float* out9) {
+    if (!angles || !out9 || (axis != 'x' && axis != 'y' && axis != 'z')) return MIPT_ERR_ARGUMENT;
+    for (size_t i = 0; i < n; ++i) rotation(axis, angles[i], out9 + 9 * i);
+    return MIPT_OK;
+}
+
+int mipt_affine_mul(size_t n, const float* a, const float* b, float* out) {
+    if (!a || !b || !out) return MIPT_ERR_ARGUMENT;
+    for (size_t i = 0; i < n; ++i) affine_mul(a + 12 * i, b + 12 * i, out + 12 * i);
+    return MIPT_OK;
+}
+
+int mipt_noise_transform(const float t[3], const float r[3], float out[12]) {
+    if (!t || !r || !out) return MIPT_ERR_ARGUMENT;
+    // Affine * Linear multiplies the linear parts and keeps the translation (src/LinearAlgebra.cpp:405-407)
+    float l[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, rot[9];
+    const char axes[3] = {'x', 'y', 'z'};
+    for (int k = 0; k < 3; ++k) {
+        rotation(axes[k], r[k], rot);
+        linear_mul(l, rot, l);
+    }
+    std::memcpy(out, l, sizeof(l));
+    out[9] = t[0];
+    out[10] = t[1];
+    out[11] = t[2];
+    return MIPT_OK;
+}
+
+int mipt_world_bounds(uint32_t kind, const float fwd[12], const float params[9], float out6[6]) {
+    if (!fwd || !params || !out6) return MIPT_ERR_ARGUMENT;
+    return world_bounds(kind, fwd, params, out6, out6 + 3) ? MIPT_OK : MIPT_ERR_ARGUMENT;
+}
+
+}   // extern "C"

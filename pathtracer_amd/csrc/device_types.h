@@ -1,0 +1,78 @@
+// Records as they lie in HBM, shared by the host packer and the kernels.
+#pragma once
+#include <stdint.h>
+
+namespace mipt {
+
+// One primitive = one 128-byte line: a lane that tests or shades a primitive fetches exactly one
+// cache line (8 x dwordx4).  Affines are Linear row-major (m[3*r+c]) followed by the translation.
+struct alignas(128) PrimRec {
+    float inv[12];      // world -> local  (Object::m_inverseTransformation)
+    float fwd[12];      // local -> world  (Object::m_transformation)
+    float p[6];         // sphere {r}; box {hx,hy,hz}; crater ball {offset}; triangle {a, b} (c in tri_c)
+    uint32_t kind;
+    uint32_t material;
+};
+static_assert(sizeof(PrimRec) == 128, "PrimRec must be one 128-byte line");
+
+// BasicMaterial padded to 64 bytes.
+struct alignas(64) MaterialRec {
+    float diffuse, specular, sharpness;
+    float albedo[3];
+    float emitted[3];
+    float transmittance, ior;
+    float internal[3];
+    float pad[2];
+};
+static_assert(sizeof(MaterialRec) == 64, "MaterialRec must be 64 bytes");
+
+// BVH2 node carrying both children's boxes (64 bytes = 4 x dwordx4).  child >= 0: node index;
+// child < 0: leaf holding primitive ~child.  An absent child has an inverted (never hit) box.
+struct alignas(64) BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t child0, child1;
+    uint32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+// World box of one SDF primitive (tested by every ray after the analytic traversal).
+struct SdfBox {
+    float lo[3];
+    uint32_t prim;
+    float hi[3];
+    uint32_t pad;
+};
+
+struct CameraRec {
+    float lin[9];
+    float tr[3];
+    float aspect, fov_scale /* tan(fov * pi/180), hoisted */, inv_focal /* 1/focalDistance */, blur_rad /* blur * max(aspect, 1/aspect) */;
+};
+
+struct SceneDev {
+    const PrimRec* prims;
+    const float* tri_c;            // 3 floats per primitive, only read for triangles (may be null)
+    const MaterialRec* materials;
+    const BvhNode* nodes;          // null when the scene has no analytic primitive
+    const SdfBox* sdf_boxes;
+    uint32_t n_sdf;
+    uint32_t n_prims;
+    float noise[12];
+};
+
+// Per-bounce queue counters of one sample batch, zeroed once per batch.
+struct BounceCounters {
+    uint32_t n_live;        // entries in the path queue feeding this bounce (bounce > 0)
+    uint32_t n_sdf;         // rays queued for the SDF march
+    uint32_t sdf_head;      // work-fetch cursor of the SDF march
+    uint32_t n_sdf_shade;   // hits queued for SDF shading
+};
+
+struct Totals {
+    unsigned long long rays, sdf_rays, sdf_shades, pad;
+};
+
+constexpr int kMaxBounces = 64;
+
+}   // namespace mipt

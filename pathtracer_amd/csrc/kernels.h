@@ -1,0 +1,51 @@
+// Launchers of the wavefront stages (defined in kernels.hip).  Every launcher only enqueues work
+// on `stream`; none of them synchronises or allocates.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+
+namespace mipt {
+
+// Per-batch working set, all in HBM, indexed by path slot unless noted.
+struct PathBuffers {
+    float4* ray_o;        // xyz origin
+    float4* ray_d;        // xyz direction
+    float4* att;          // xyz attenuation (throughput)
+    float4* rad;          // xyz radiance gathered so far
+    unsigned long long* hit_key;   // (float bits of t) << 32 | primitive, ~0 = miss
+    float4* hit_pos;      // xyz world hit position as Object::hitRay returns it
+    uint32_t* queue[2];   // live path slots, ping-pong per bounce
+    uint32_t* sdf_queue;  // slots whose ray entered an SDF primitive's box
+    uint32_t* sdf_shade_queue;   // slots whose closest hit is an SDF primitive
+    BounceCounters* counters;    // kMaxBounces + 1 entries
+    Totals* totals;
+};
+
+struct BatchParams {
+    uint32_t n_slots;       // paths in this batch = n_pix * samples_in_batch
+    uint32_t n_pix;
+    uint32_t width, height;
+    uint32_t first_sample;  // global sample index of sample 0 of this batch
+    uint32_t flags;
+    uint64_t seed;
+};
+
+void launch_generate(hipStream_t, const CameraRec&, const BatchParams&, const PathBuffers&);
+void launch_extend(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, int bvh_depth);
+void launch_sdf_march(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce);
+void launch_shade(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, uint32_t max_bounces);
+void launch_shade_sdf(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, uint32_t max_bounces);
+void launch_finish_batch(hipStream_t, const PathBuffers&, uint32_t bounces, uint32_t n_slots);
+// frame[pix] += sum over the batch's samples, in sample order (the `acc +=` of src/Renderer.cpp:97-99)
+void launch_accumulate(hipStream_t, const BatchParams&, const PathBuffers&, float* frame_sum);
+void launch_scale(hipStream_t, const float* in, float k, size_t n, float* out);
+void launch_load_rays(hipStream_t, const float* pos3, const float* dir3, uint32_t n, const PathBuffers&);
+void launch_export_rad(hipStream_t, const PathBuffers&, uint32_t n, float* out3);
+void launch_tonemap_filmic(hipStream_t, const float* in, float* out, size_t n_floats);
+// Reinhard: scratch holds 3 floats per block of the reduction plus 4 result floats
+void launch_tonemap_reinhard(hipStream_t, const float* in, float* out, size_t width, size_t height, float* scratch, size_t scratch_floats);
+size_t reinhard_scratch_floats();
+
+}   // namespace mipt

@@ -1,0 +1,1082 @@
+// Wavefront path-tracing stages for gfx950 (MI355X): generate -> [extend -> sdf_march -> shade ->
+// shade_sdf] per bounce -> accumulate, plus the tone mappers.
+//
+// Numerics.  This file is compiled with -ffp-contract=off and HIP's correctly rounded fp32 divide and
+// square root, so everything in the "exact" part evaluates the reference's expressions in the
+// reference's order and returns the same bits as a baseline x86-64 build of it: camera rays, the
+// affine wrapping of Object::hitRay / deflectRay, the analytic intersections and normals, the material.
+// The crater-ball SDF (tanh, pow, an 8-octave noise: a few thousand flops per evaluation, the
+// VALU-bound part of the demo scene) lives in the "fast" part, where contraction to FMA and the
+// hardware rcp / rsq / exp2 / log2 are allowed; its results agree with the reference to ~1e-6.
+//
+// Citations are file:line of the reference checkout (timstr/pathtracer).
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace mipt {
+
+#pragma clang fp contract(off)
+
+// =============================================================================================
+// exact part
+// =============================================================================================
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, float t) { return {a.x * t, a.y * t, a.z * t}; }
+__device__ __forceinline__ f3 operator*(float t, f3 a) { return {a.x * t, a.y * t, a.z * t}; }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 u, f3 v) {
+    return {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+}
+__device__ __forceinline__ float norm_sq(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+__device__ __forceinline__ float norm(f3 a) { return sqrtf(norm_sq(a)); }
+__device__ __forceinline__ f3 unit(f3 a) {   // Vec::unit src/LinearAlgebra.cpp:25-29
+    const float l = norm(a);
+    return {a.x / l, a.y / l, a.z / l};
+}
+// Linear * Vec = column(0)*x + column(1)*y + column(2)*z  (src/LinearAlgebra.cpp:380-382)
+__device__ __forceinline__ f3 lin_mul(const float* m, f3 v) {
+    return {(m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[3] * v.x + m[4] * v.y) + m[5] * v.z,
+            (m[6] * v.x + m[7] * v.y) + m[8] * v.z};
+}
+__device__ __forceinline__ f3 aff_pos(const float* a, f3 p) {   // Affine * Pos :401-403
+    const f3 l = lin_mul(a, p);
+    return {l.x + a[9], l.y + a[10], l.z + a[11]};
+}
+__device__ __forceinline__ f3 ld3(float4 v) { return {v.x, v.y, v.z}; }
+__device__ __forceinline__ float4 st4(f3 v, float w = 0.0f) { return make_float4(v.x, v.y, v.z, w); }
+
+// ---- counter-based random numbers: value = f(seed, pixel, sample, stage, k) ------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z ^= z >> 30;
+    z *= 0xbf58476d1ce4e5b9ull;
+    z ^= z >> 27;
+    z *= 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return z;
+}
+struct Rng {
+    uint64_t key;
+    uint32_t ctr;   // stage * 64 + k + 1
+    __device__ __forceinline__ Rng(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stage)
+        : key(mix64(((static_cast<uint64_t>(pixel) << 32) | sample) + seed * 0x9e3779b97f4a7c15ull)), ctr(stage * 64u + 1u) {}
+    __device__ __forceinline__ float u01() {
+        const uint64_t r = mix64(key + static_cast<uint64_t>(ctr++) * 0x9e3779b97f4a7c15ull);
+        return static_cast<float>(static_cast<uint32_t>(r >> 40)) * (1.0f / 16777216.0f);
+    }
+    // std::uniform_real_distribution<float>{a, b}: (b - a) * u + a
+    __device__ __forceinline__ float uniform(float a, float b) { return (b - a) * u01() + a; }
+};
+
+// ---- hit keys: closest = smallest 64-bit key; ties go to the lower primitive index -----------
+__device__ __forceinline__ uint32_t ordered_bits(float t) {
+    const uint32_t b = __float_as_uint(t);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ unsigned long long make_key(float t, uint32_t prim) {
+    return (static_cast<unsigned long long>(ordered_bits(t)) << 32) | prim;
+}
+constexpr unsigned long long kMissKey = ~0ull;
+
+// ---- analytic intersections (src/Geometry.cpp) -------------------------------------------------
+constexpr float kGeoEps = 1e-3f;   // :8
+
+__device__ __forceinline__ bool hit_sphere(f3 o, f3 d, float radius, f3& out) {   // :173-201
+    const float a = norm_sq(d);
+    const float b = 2.0f * dot(d, o);
+    const float c = norm_sq(o) - (radius * radius);
+    const float disc = b * b - 4.0f * a * c;
+    if (disc <= 0.0f) return false;
+    const float sq = sqrtf(disc);
+    const float t0 = (-b - sq) / (2.0f * a);
+    const float t1 = (-b + sq) / (2.0f * a);
+    float t;
+    if (t0 > kGeoEps) {
+        t = (t1 > kGeoEps) ? fminf(t0, t1) : t0;
+    } else {
+        if (t1 > kGeoEps) t = t1;
+        else return false;
+    }
+    out = o + t * d;
+    return true;
+}
+
+// intersect(Ray, Rectangle) :203-252.  Faces whose direction component is below 1e-3 in magnitude are
+// skipped, t > 0 carries no epsilon, and from inside the exit face is returned.
+__device__ __forceinline__ bool hit_rect(f3 o, f3 d, f3 half, f3& out) {
+    const f3 lo = -o - half;
+    const f3 hi = -o + half;
+    float best = 0.0f;
+    bool have = false;
+#define MIPT_FACE(DK, CK, DA, LA, HA, DB, LB, HB)                                  \
+    if (fabsf(DK) >= kGeoEps) {                                                    \
+        const float t = (CK) / (DK);                                               \
+        if (t > 0.0f) {                                                            \
+            const float va = (DA) * t, vb = (DB) * t;                              \
+            if (va >= (LA) && va <= (HA) && vb >= (LB) && vb <= (HB)) {            \
+                best = have ? fminf(best, t) : t;                                  \
+                have = true;                                                       \
+            }                                                                      \
+        }                                                                          \
+    }
+    MIPT_FACE(d.x, lo.x, d.y, lo.y, hi.y, d.z, lo.z, hi.z)
+    MIPT_FACE(d.x, hi.x, d.y, lo.y, hi.y, d.z, lo.z, hi.z)
+    MIPT_FACE(d.y, lo.y, d.x, lo.x, hi.x, d.z, lo.z, hi.z)
+    MIPT_FACE(d.y, hi.y, d.x, lo.x, hi.x, d.z, lo.z, hi.z)
+    MIPT_FACE(d.z, lo.z, d.x, lo.x, hi.x, d.y, lo.y, hi.y)
+    MIPT_FACE(d.z, hi.z, d.x, lo.x, hi.x, d.y, lo.y, hi.y)
+#undef MIPT_FACE
+    if (!have) return false;
+    out = o + (best * d);
+    return true;
+}
+
+__device__ __forceinline__ bool hit_triangle(f3 o, f3 d, f3 a, f3 b, f3 c, f3& out) {   // :146-171
+    const f3 e1 = b - a, e2 = c - a;
+    const f3 h = cross(d, e2);
+    const float det = dot(e1, h);
+    if (fabsf(det) < kGeoEps) return false;
+    const float f = 1.0f / det;
+    const f3 s = o - a;
+    const float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    const f3 q = cross(s, e1);
+    const float v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    const float t = f * dot(e2, q);
+    if (!(t > kGeoEps)) return false;
+    out = o + t * d;
+    return true;
+}
+
+__device__ __forceinline__ bool inside_rect(f3 p, f3 half) {   // :267-272
+    return (fabsf(p.x) <= half.x) && (fabsf(p.y) <= half.y) && (fabsf(p.z) <= half.z);
+}
+
+__device__ __forceinline__ f3 rect_normal(f3 p, f3 half) {   // Rectangle::normal :77-103
+    const float ax = fabsf(p.x / half.x), ay = fabsf(p.y / half.y), az = fabsf(p.z / half.z);
+    const float sx = p.x > 0.0f ? 1.0f : -1.0f, sy = p.y > 0.0f ? 1.0f : -1.0f, sz = p.z > 0.0f ? 1.0f : -1.0f;
+    if (ax > ay) {
+        if (ax > az) return mk3(sx, 0.0f, 0.0f);
+        return mk3(0.0f, 0.0f, sz);
+    }
+    if (ay > az) return mk3(0.0f, sy, 0.0f);
+    return mk3(0.0f, 0.0f, sz);
+}
+
+// ---- material (src/BasicMaterial.cpp:97-159) and samplers (src/Geometry.cpp:290-341) ------------
+__device__ __forceinline__ f3 mirror(f3 in, f3 n) { return in - (2.0f * (dot(in, n) * n)); }   // bounce()
+
+__device__ __forceinline__ f3 cosine_hemisphere(f3 n, Rng& rng) {
+    n = unit(n);
+    float x, y, l2;
+    do {
+        x = rng.uniform(-1.0f, 1.0f);
+        y = rng.uniform(-1.0f, 1.0f);
+        l2 = (x * x) + (y * y);
+    } while (l2 > 1.0f);
+    const float z = sqrtf(1.0f - l2);
+    // orthogonalPair :290-299 (normalises its argument once more; the 0.1 is a double literal)
+    const f3 v = unit(n);
+    const f3 c = cross(v, mk3(1.0f, 0.0f, 0.0f));
+    const bool aligned_to_x = static_cast<double>(norm_sq(c)) < 0.1;
+    const f3 w = aligned_to_x ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
+    const f3 v1 = cross(w, v);
+    const f3 v2 = cross(v1, v);
+    return (z * n) + (x * unit(v1)) + (y * unit(v2));
+}
+
+struct Bounce {
+    f3 emitted, attenuation, dir;
+};
+
+__device__ __forceinline__ Bounce deflect(const MaterialRec& m, f3 in, f3 n, Rng& rng) {
+    Bounce b;
+    const float s = dot(in, n);
+    if (s >= 0.0f) {   // struck from inside
+        const f3 v = unit(in + ((dot(in, n) * (1.0f - m.ior)) * n));
+        if (dot(v, n) >= 0.0f) {
+            b.emitted = mk3(0.0f, 0.0f, 0.0f);
+            b.attenuation = mk3(1.0f, 1.0f, 1.0f);
+            b.dir = v;
+        } else {
+            b.emitted = mk3(0.0f, 1.0f, 1.0f);
+            b.attenuation = mk3(0.0f, 0.0f, 0.0f);
+            b.dir = mirror(in, -n);
+        }
+        return b;
+    }
+    b.emitted = mk3(m.emitted[0], m.emitted[1], m.emitted[2]);
+    b.attenuation = mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    const float reflection = m.diffuse + m.specular;
+    const float options = reflection + m.transmittance;
+    const float which = rng.uniform(0.0f, options);
+    if (which < reflection) {
+        if (which < m.diffuse) {
+            b.dir = cosine_hemisphere(n, rng);
+        } else {
+            const f3 sc = (1.0f - m.sharpness) * cosine_hemisphere(n, rng);
+            b.dir = unit(mirror(in, n) + sc);
+        }
+    } else {
+        b.dir = unit(in + ((dot(in, n) * (1.0f - 1.0f / m.ior)) * n));
+    }
+    return b;
+}
+
+// ---- loads -----------------------------------------------------------------------------------
+struct PrimRegs {
+    float inv[12], fwd[12], p[6];
+    uint32_t kind, material;
+};
+__device__ __forceinline__ void load_prim(const PrimRec* prims, uint32_t i, PrimRegs& r) {
+    const float4* src = reinterpret_cast<const float4*>(prims + i);
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = src[k];
+    r.inv[0] = v[0].x; r.inv[1] = v[0].y; r.inv[2] = v[0].z; r.inv[3] = v[0].w;
+    r.inv[4] = v[1].x; r.inv[5] = v[1].y; r.inv[6] = v[1].z; r.inv[7] = v[1].w;
+    r.inv[8] = v[2].x; r.inv[9] = v[2].y; r.inv[10] = v[2].z; r.inv[11] = v[2].w;
+    r.fwd[0] = v[3].x; r.fwd[1] = v[3].y; r.fwd[2] = v[3].z; r.fwd[3] = v[3].w;
+    r.fwd[4] = v[4].x; r.fwd[5] = v[4].y; r.fwd[6] = v[4].z; r.fwd[7] = v[4].w;
+    r.fwd[8] = v[5].x; r.fwd[9] = v[5].y; r.fwd[10] = v[5].z; r.fwd[11] = v[5].w;
+    r.p[0] = v[6].x; r.p[1] = v[6].y; r.p[2] = v[6].z; r.p[3] = v[6].w;
+    r.p[4] = v[7].x; r.p[5] = v[7].y;
+    r.kind = __float_as_uint(v[7].z);
+    r.material = __float_as_uint(v[7].w);
+}
+
+// Object::hitRay (src/Object.cpp:22-33) for the analytic kinds: local ray (direction not
+// renormalised) -> *::hitLocalRay -> world hit position; t = (hit - ray.pos) . ray.dir.
+__device__ __forceinline__ bool hit_analytic(const PrimRegs& pr, const float* tri_c, uint32_t prim, f3 o, f3 d, f3& world, float& t) {
+    const f3 lo = aff_pos(pr.inv, o);
+    const f3 ld = lin_mul(pr.inv, d);
+    f3 lh;
+    bool hit = false;
+    if (pr.kind == 0u) {
+        hit = hit_sphere(lo, ld, pr.p[0], lh);
+    } else if (pr.kind == 1u) {
+        hit = hit_rect(lo, ld, mk3(pr.p[0], pr.p[1], pr.p[2]), lh);
+    } else if (pr.kind == 2u) {
+        const f3 c = mk3(tri_c[3 * prim], tri_c[3 * prim + 1], tri_c[3 * prim + 2]);
+        hit = hit_triangle(lo, ld, mk3(pr.p[0], pr.p[1], pr.p[2]), mk3(pr.p[3], pr.p[4], pr.p[5]), c, lh);
+    }
+    if (!hit) return false;
+    world = aff_pos(pr.fwd, lh);
+    t = dot(world - o, d);
+    return true;
+}
+
+// Conservative ray / box test in ray-parameter units.  NaNs from 0 * inf drop out of fmin/fmax, which
+// only ever widens the interval.
+__device__ __forceinline__ bool slab(f3 o, f3 inv_d, const float* lo, const float* hi, float t_limit, float& t_near) {
+    const float x0 = (lo[0] - o.x) * inv_d.x, x1 = (hi[0] - o.x) * inv_d.x;
+    const float y0 = (lo[1] - o.y) * inv_d.y, y1 = (hi[1] - o.y) * inv_d.y;
+    const float z0 = (lo[2] - o.z) * inv_d.z, z1 = (hi[2] - o.z) * inv_d.z;
+    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * 1.0000005f;
+    t_near = tn;
+    return tn <= tf && tn <= t_limit;
+}
+
+// =============================================================================================
+// generate: Renderer::doWork's sample set-up (src/Renderer.cpp:72-94) + Camera::getViewRay
+// (src/Camera.cpp:65-81).  One thread per path slot; slot = sample_in_batch * n_pix + pixel, so a wave
+// covers 64 neighbouring pixels of one sample and every store is a coalesced 1 KiB line.
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_generate(CameraRec cam, BatchParams bp, PathBuffers pb) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const float max_w = static_cast<float>(bp.width - 1), max_h = static_cast<float>(bp.height - 1);
+    const float dx = 1.0f / max_w, dy = 1.0f / max_h;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < bp.n_slots; slot += stride) {
+        const uint32_t s_local = slot / bp.n_pix;
+        const uint32_t pix = slot - s_local * bp.n_pix;
+        const uint32_t y = pix / bp.width, x = pix - y * bp.width;
+        Rng rng(bp.seed, pix, bp.first_sample + s_local, 0u);
+        float sx = static_cast<float>(x) / max_w;
+        float sy = static_cast<float>(y) / max_h;
+        if (!(bp.flags & 1u)) {
+            sx = sx + rng.uniform(-0.5f * dx, 0.5f * dx);
+            sy = sy + rng.uniform(-0.5f * dy, 0.5f * dy);
+        }
+        const float vx = sx * 2.0f - 1.0f;
+        const float vy = sy * 2.0f - 1.0f;
+        const f3 sp = cam.aspect > 1.0f ? mk3(vx, vy / cam.aspect, 0.0f) : mk3(vx * cam.aspect, vy, 0.0f);
+        float rx = 0.0f, ry = 0.0f;
+        if (cam.blur_rad != 0.0f) {   // randomPointInCircle src/Geometry.cpp:278-288 (draws k = 2, 3, ...)
+            rng.ctr = 3u;
+            do {
+                rx = rng.uniform(-1.0f, 1.0f);
+                ry = rng.uniform(-1.0f, 1.0f);
+            } while (rx * rx + ry * ry > 1.0f);
+        }
+        const f3 blur = mk3(rx * cam.blur_rad, ry * cam.blur_rad, 0.0f);
+        const f3 view = mk3(cam.fov_scale * sp.x, cam.fov_scale * sp.y, 1.0f) + blur * cam.inv_focal;
+        const f3 dir = unit(lin_mul(cam.lin, view));
+        const f3 l = lin_mul(cam.lin, sp - blur);
+        const f3 pos = mk3(l.x + cam.tr[0], l.y + cam.tr[1], l.z + cam.tr[2]);
+        pb.ray_o[slot] = st4(pos);
+        pb.ray_d[slot] = st4(dir);
+        pb.att[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        pb.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+// =============================================================================================
+// extend: closest hit over the analytic primitives (ObjectTree::Tree::hit, src/ObjectTree.cpp:22-88,
+// with real culling) and the SDF boxes.  One lane per live ray; the traversal stack is a column of LDS
+// dwords per lane (entry e of lane l at e * blockDim + l: conflict-free for ds_read/write_b32).
+// =============================================================================================
+template <int STACK>
+__global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
+    __shared__ int s_stack[STACK * 256];
+    const uint32_t n = bounce == 0 ? bp.n_slots : pb.counters[bounce].n_live;
+    const uint32_t* queue = bounce == 0 ? nullptr : pb.queue[bounce & 1];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    int* stack = s_stack + threadIdx.x;
+    uint32_t n_sdf_rays = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t slot = queue ? queue[i] : i;
+        const f3 o = ld3(pb.ray_o[slot]);
+        const f3 d = ld3(pb.ray_d[slot]);
+        const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        // Hits are ranked by t = (hit - o).d as the reference ranks them; boxes are culled in
+        // ray-parameter units, t / |d|^2, with a relative and absolute margin.
+        const float inv_len2 = 1.0f / norm_sq(d);
+        unsigned long long best = kMissKey;
+        f3 best_pos = mk3(0.0f, 0.0f, 0.0f);
+        float limit = 3.0e38f;
+        if (sc.nodes) {
+            int sp = 0;
+            int cur = 0;
+            for (;;) {
+                const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
+                const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+                const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y};
+                const float lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
+                int c0 = __float_as_int(e.x), c1 = __float_as_int(e.y);
+                float t0, t1;
+                bool h0 = slab(o, inv_d, lo0, hi0, limit, t0);
+                bool h1 = slab(o, inv_d, lo1, hi1, limit, t1);
+                if (h0 && h1 && t1 < t0) {   // nearer child first
+                    const int tc = c0; c0 = c1; c1 = tc;
+                    const float tt = t0; t0 = t1; t1 = tt;
+                } else if (!h0 && h1) {
+                    c0 = c1; t0 = t1; h0 = true; h1 = false;
+                }
+                int next = -1;
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const bool h = side == 0 ? h0 : h1;
+                    const int ch = side == 0 ? c0 : c1;
+                    const float tn = side == 0 ? t0 : t1;
+                    if (!h || tn > limit) continue;
+                    if (ch < 0) {
+                        const uint32_t prim = static_cast<uint32_t>(~ch);
+                        PrimRegs pr;
+                        load_prim(sc.prims, prim, pr);
+                        f3 w;
+                        float t;
+                        if (hit_analytic(pr, sc.tri_c, prim, o, d, w, t)) {
+                            const unsigned long long key = make_key(t, prim);
+                            if (key < best) {
+                                best = key;
+                                best_pos = w;
+                                limit = fmaxf(t, 0.0f) * inv_len2 * 1.00001f + 1e-6f;
+                            }
+                        }
+                    } else if (next < 0) {
+                        next = ch;
+                    } else {
+                        stack[sp * 256] = ch;
+                        ++sp;
+                    }
+                }
+                if (next < 0) {
+                    if (sp == 0) break;
+                    --sp;
+                    next = stack[sp * 256];
+                }
+                cur = next;
+            }
+        }
+        pb.hit_key[slot] = best;
+        pb.hit_pos[slot] = st4(best_pos);
+        // Does the ray reach any SDF primitive's box before its best analytic hit?
+        bool wants_sdf = false;
+        for (uint32_t k = 0; k < sc.n_sdf; ++k) {
+            float tn;
+            wants_sdf = wants_sdf || slab(o, inv_d, sc.sdf_boxes[k].lo, sc.sdf_boxes[k].hi, limit, tn);
+        }
+        if (wants_sdf) {
+            // wave-aggregated append: one atomic per wave
+            const unsigned long long m = __ballot(1);
+            const uint32_t lane = __lane_id();
+            const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+            uint32_t base = 0;
+            if (rank == 0) base = atomicAdd(&pb.counters[bounce].n_sdf, static_cast<uint32_t>(__popcll(m)));
+            base = __shfl(base, __ffsll(static_cast<long long>(m)) - 1);
+            pb.sdf_queue[base + rank] = slot;
+            ++n_sdf_rays;
+        }
+    }
+    if (n_sdf_rays) atomicAdd(&pb.totals->sdf_rays, static_cast<unsigned long long>(n_sdf_rays));
+}
+
+// =============================================================================================
+// fast part: crater-ball SDF (PathTracerDemo.cpp:26-116, 361-466)
+// =============================================================================================
+#pragma clang fp contract(fast)
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+// tanh(c) = 1 - 2 / (exp(2c) + 1); absolute error ~1e-7, which is what the SDF terms it feeds need
+__device__ __forceinline__ float fast_tanh(float c) {
+    const float e = fast_exp2(c * 2.885390081777927f);   // 2 / ln 2
+    return 1.0f - 2.0f * fast_rcp(e + 1.0f);
+}
+
+// noise() :56-70.  triangle(x) = -1 + 4 |x - 0.25 - floor(x + 0.25)| = 4 |fract(x + 0.25) - 0.5| - 1, so
+// the octave sum is 4 * sum_i k_i (a_x + a_y + a_z) - 3 * sum_i k_i with a = |fract(. + 0.25) - 0.5|.
+// The per-octave `location *= 1.1` is folded into the next octave's matrix.
+__device__ __forceinline__ float fbm_noise(const float (&T)[12], f3 p) {
+    float acc = 0.0f;
+    float k = 0.02f;
+    float x = fmaf(T[0], p.x, fmaf(T[1], p.y, fmaf(T[2], p.z, T[9])));
+    float y = fmaf(T[3], p.x, fmaf(T[4], p.y, fmaf(T[5], p.z, T[10])));
+    float z = fmaf(T[6], p.x, fmaf(T[7], p.y, fmaf(T[8], p.z, T[11])));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float ax = fabsf(__builtin_amdgcn_fractf(x + 0.25f) - 0.5f);
+        const float ay = fabsf(__builtin_amdgcn_fractf(y + 0.25f) - 0.5f);
+        const float az = fabsf(__builtin_amdgcn_fractf(z + 0.25f) - 0.5f);
+        acc = fmaf(k, (ax + ay) + az, acc);
+        k *= 0.9f;
+        if (i < 7) {
+            const float sx = 1.1f * x, sy = 1.1f * y, sz = 1.1f * z;
+            x = fmaf(T[0], sx, fmaf(T[1], sy, fmaf(T[2], sz, T[9])));
+            y = fmaf(T[3], sx, fmaf(T[4], sy, fmaf(T[5], sz, T[10])));
+            z = fmaf(T[6], sx, fmaf(T[7], sy, fmaf(T[8], sz, T[11])));
+        }
+    }
+    // sum_i 0.02 * 0.9^i, i < 8
+    return 4.0f * acc - 3.0f * 0.11390656f;
+}
+
+// One cell of for_each_nearby_scattered_point :79-116: hashed, jittered lattice point.  The reference
+// forms the jitter through double; fmaf(scatter/2, m, g) rounds the same exact value once.
+__device__ __forceinline__ f3 scattered_cell(f3 g, float half_scatter, uint32_t& hash) {
+    uint32_t h = static_cast<uint32_t>(static_cast<int>(g.x)) * 885889u + static_cast<uint32_t>(static_cast<int>(g.y)) * 745273u +
+                 static_cast<uint32_t>(static_cast<int>(g.z)) * 1220689u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        h |= (h & 0x0f0f0f0fu) << 4;
+        h *= 31u;
+    }
+    hash = h;
+    const float mx = static_cast<float>(h & 0x3ffu) * (1.0f / 512.0f) - 1.0f;
+    const float my = static_cast<float>((h >> 10) & 0x3ffu) * (1.0f / 512.0f) - 1.0f;
+    const float mz = static_cast<float>((h >> 20) & 0x3ffu) * (1.0f / 512.0f) - 1.0f;
+    return mk3(fmaf(half_scatter, mx, g.x), fmaf(half_scatter, my, g.y), fmaf(half_scatter, mz, g.z));
+}
+
+// Projects a lattice point onto the sphere of radius `scale` about `off` and reports whether it lies
+// within sqrt(0.1) of that sphere (the `(point_on_sphere - point).normSquared() < 0.1f` tests).
+__device__ __forceinline__ bool project_cell(f3 point, f3 off, float scale, f3& on_sphere) {
+    const f3 v = point - off;
+    const float il = fast_rsq(norm_sq(v));
+    on_sphere = mk3(fmaf(v.x, il * scale, off.x), fmaf(v.y, il * scale, off.y), fmaf(v.z, il * scale, off.z));
+    return norm_sq(on_sphere - point) < 0.1f;
+}
+
+// CraterBallObject::signedDistance :361-466 for a point whose sphere distance s = |pos| - 0.5 is
+// already known to be <= 0.1 (the far field returns s itself).
+__device__ __forceinline__ float craterball_near(const float (&NT)[12], f3 off, f3 pos, float s) {
+    const float il = fast_rsq(norm_sq(pos));
+    const f3 u = mk3(-pos.x * il, -pos.y * il, -pos.z * il);
+    float crater = 0.0f, tiny = 0.0f, fallout = 0.0f;
+    uint32_t min_age = 0xffffu;   // ages are compared as their 16-bit integers (age = bits / 65535)
+
+    {   // big craters :375-409 -- 4^3 cells.  Pass 1 marks the cells inside the shell in a 64-bit mask;
+        // pass 2 visits the marked cells in the reference's order, so the loop trip count of a wave is
+        // the largest popcount among its lanes rather than 64.
+        const float scale = 2.0f;
+        const f3 query = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
+        const f3 origin = mk3(floorf(query.x), floorf(query.y), floorf(query.z));
+        unsigned long long mask = 0ull;
+        for (int c = 0; c < 64; ++c) {
+            const f3 g = mk3(origin.x + static_cast<float>((c >> 4) - 1), origin.y + static_cast<float>(((c >> 2) & 3) - 1),
+                             origin.z + static_cast<float>((c & 3) - 1));
+            uint32_t hash;
+            const f3 point = scattered_cell(g, 0.3f, hash);
+            f3 on;
+            if (project_cell(point, off, scale, on)) mask |= 1ull << c;
+        }
+        while (mask) {
+            const int c = __ffsll(static_cast<long long>(mask)) - 1;
+            mask &= mask - 1ull;
+            const f3 g = mk3(origin.x + static_cast<float>((c >> 4) - 1), origin.y + static_cast<float>(((c >> 2) & 3) - 1),
+                             origin.z + static_cast<float>((c & 3) - 1));
+            uint32_t hash;
+            const f3 point = scattered_cell(g, 0.3f, hash);
+            f3 on;
+            project_cell(point, off, scale, on);
+            const float t = static_cast<float>(hash & 0xffffu) * (1.0f / 65535.0f);
+            const float size = fmaf(0.4f * t, t, 0.05f);
+            const f3 qv = query - on;
+            const float dist2 = norm_sq(qv);
+            const float dist = dist2 * fast_rsq(fmaxf(dist2, 1e-30f));
+            const float c20 = 20.0f * (dist - size);
+            float depth = fast_tanh(c20);
+            if (c20 > 1e-3f) depth = 0.9f * t * depth * fast_rcp(0.02f * fast_rcp(c20) + c20 * c20);
+            crater = fmaf(-0.02f, depth, crater);
+            if (dist >= size) {
+                // pow(0, y) = 0 for the y in [1, 3] that occurs here, so a zero linear falloff adds
+                // exactly nothing and both noise calls can be skipped
+                const float lin = fmaxf(0.0f, 1.2f - dist * fast_rcp(size * 5.0f));
+                if (lin > 0.0f) {
+                    const float idist = fast_rsq(fmaxf(dist2, 1e-30f));
+                    const f3 dirv = mk3(qv.x * idist, qv.y * idist, qv.z * idist);
+                    const float n1 = fbm_noise(NT, mk3(fmaf(3.0f * size, dirv.x, on.x), fmaf(3.0f * size, dirv.y, on.y), fmaf(3.0f * size, dirv.z, on.z)));
+                    const float n2 = fbm_noise(NT, mk3(fmaf(40.0f * size, dirv.x, on.x), fmaf(40.0f * size, dirv.y, on.y), fmaf(40.0f * size, dirv.z, on.z)));
+                    const float falloff = fast_exp2((2.0f + 3.0f * n1) * fast_log2(lin));
+                    fallout = fmaf(0.1f * falloff * (0.2f + 0.4f * depth), n2, fallout);
+                }
+            } else {
+                min_age = min(min_age, hash >> 16);
+            }
+        }
+    }
+    {   // small craters :412-437 -- 2^3 cells, order matters through min_age
+        const float scale = 10.0f;
+        const f3 query = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
+        const f3 origin = mk3(floorf(query.x), floorf(query.y), floorf(query.z));
+#pragma unroll 1
+        for (int c = 0; c < 8; ++c) {
+            const f3 g = mk3(origin.x + static_cast<float>(c >> 2), origin.y + static_cast<float>((c >> 1) & 1), origin.z + static_cast<float>(c & 1));
+            uint32_t hash;
+            const f3 point = scattered_cell(g, 0.5f, hash);
+            const uint32_t age = hash >> 16;
+            if (age > min_age) continue;
+            f3 on;
+            if (!project_cell(point, off, scale, on)) continue;
+            const float t = static_cast<float>(hash & 0xffffu) * (1.0f / 65535.0f);
+            const float size = fmaf(0.35f * t, t, 0.05f);
+            const float dist = sqrtf(norm_sq(query - on));
+            const float c50 = 50.0f * (dist - size);
+            if (c50 < 0.0f) {
+                min_age = min(min_age, age);
+                crater = fmaxf(-0.005f * fast_tanh(c50), crater);
+            }
+        }
+    }
+    {   // tiny craters :440-463
+        const float scale = 60.0f;
+        const f3 query = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
+        const f3 origin = mk3(floorf(query.x), floorf(query.y), floorf(query.z));
+#pragma unroll 1
+        for (int c = 0; c < 8; ++c) {
+            const f3 g = mk3(origin.x + static_cast<float>(c >> 2), origin.y + static_cast<float>((c >> 1) & 1), origin.z + static_cast<float>(c & 1));
+            uint32_t hash;
+            const f3 point = scattered_cell(g, 0.5f, hash);
+            f3 on;
+            if (!project_cell(point, off, scale, on)) continue;
+            if ((hash >> 16) > min_age) continue;
+            const float t = static_cast<float>(hash & 0xffffu) * (1.0f / 65535.0f);
+            const float size = fmaf(0.35f, t, 0.02f);
+            const float dist = sqrtf(norm_sq(query - on));
+            tiny = fmaxf(-0.004f * size * (-0.5f + 0.5f * fast_tanh(50.0f * (dist - size))), tiny);
+        }
+    }
+    const f3 q = pos + off;
+    return s + crater + tiny + fallout + 0.01f * fbm_noise(NT, mk3(q.x * 20.0f, q.y * 20.0f, q.z * 20.0f)) +
+           0.4f * fbm_noise(NT, mk3(q.x * 1.5f, q.y * 1.5f, q.z * 1.5f));
+}
+
+#pragma clang fp contract(off)
+
+// =============================================================================================
+// sdf_march: SDFObjectCRTP::hitLocalRay (include/Object.hpp:135-167) as a per-lane state machine.
+// Persistent waves pull rays from the SDF queue; a lane that finishes pulls the next ray, so the
+// expensive near-field evaluations always run with as many lanes as the queue can supply.  Each
+// round first lets every lane take its cheap far-field steps (sdf = |p| - 0.5 when that exceeds 0.1),
+// then all lanes that still need one evaluate the near field together.
+// =============================================================================================
+struct March {
+    f3 p, dir;          // local frame
+    float d;
+    uint32_t iter;
+    bool first, sign;
+};
+
+// One iteration of the reference's loop body given the SDF value d2 at m.p.  Returns 0 to continue,
+// 1 for a hit (m.p is the hit), 2 for a miss.  The reference evaluates the SDF once before the loop
+// and again, at the same point, in iteration 0; both values are d2 here.
+__device__ __forceinline__ int march_step(March& m, float d2) {
+    if (m.first) {
+        m.d = d2;
+        m.sign = d2 > 0.0f;
+        m.first = false;
+    }
+    if ((d2 > 0.0f) != m.sign) {
+        m.d *= 0.5f;
+        m.p = m.p - m.d * m.dir;
+    } else {
+        m.d = d2;
+        if (fabsf(m.d) < 1e-4f) return 1;
+        m.p = m.p + fabsf(m.d) * m.dir;
+        if (!inside_rect(m.p, mk3(1.0f, 1.0f, 1.0f))) return 2;   // CraterBallObject::localBoundingBox :474-479
+    }
+    return ++m.iter >= 256u ? 2 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
+    const uint32_t n = pb.counters[bounce].n_sdf;
+    if (n == 0) return;
+    uint32_t* head = &pb.counters[bounce].sdf_head;
+    constexpr int IDLE = 0, SETUP = 1, MARCH = 2;
+    int state = IDLE;
+    bool exhausted = false;
+    uint32_t slot = 0, k = 0, prim = 0;
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv_d = mk3(0, 0, 0), off = mk3(0, 0, 0), best_pos = mk3(0, 0, 0);
+    float inv_len2 = 0.0f, limit = 0.0f;
+    unsigned long long best = kMissKey;
+    bool improved = false;
+    March m;
+    m.p = m.dir = mk3(0, 0, 0);
+    m.d = 0.0f;
+    m.iter = 0;
+    m.first = m.sign = false;
+
+    for (;;) {
+        // (1) idle lanes fetch a ray
+        if (state == IDLE && !exhausted) {
+            const uint32_t i = atomicAdd(head, 1u);
+            if (i < n) {
+                slot = pb.sdf_queue[i];
+                o = ld3(pb.ray_o[slot]);
+                d = ld3(pb.ray_d[slot]);
+                inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                inv_len2 = 1.0f / norm_sq(d);
+                best = pb.hit_key[slot];
+                best_pos = ld3(pb.hit_pos[slot]);
+                limit = 3.0e38f;
+                if (best != kMissKey) {
+                    // recover t from the key to cull boxes behind the analytic hit
+                    const uint32_t ob = static_cast<uint32_t>(best >> 32);
+                    const uint32_t fb = (ob & 0x80000000u) ? (ob ^ 0x80000000u) : ~ob;
+                    limit = fmaxf(__uint_as_float(fb), 0.0f) * inv_len2 * 1.00001f + 1e-6f;
+                }
+                improved = false;
+                k = 0;
+                state = SETUP;
+            } else {
+                exhausted = true;
+            }
+        }
+        // (2) set up the march on the next SDF primitive whose box the ray reaches
+        while (state == SETUP) {
+            if (k == sc.n_sdf) {
+                if (improved) {
+                    pb.hit_key[slot] = best;
+                    pb.hit_pos[slot] = st4(best_pos);
+                }
+                state = IDLE;
+                break;
+            }
+            const SdfBox bx = sc.sdf_boxes[k];
+            float tn;
+            if (slab(o, inv_d, bx.lo, bx.hi, limit, tn)) {
+                prim = bx.prim;
+                const PrimRec* pr = sc.prims + prim;
+                const f3 lo = aff_pos(pr->inv, o);
+                const f3 ld = lin_mul(pr->inv, d);
+                off = mk3(pr->p[0], pr->p[1], pr->p[2]);
+                bool ok = true;
+                f3 p0 = lo;
+                if (!inside_rect(lo, mk3(1.0f, 1.0f, 1.0f))) ok = hit_rect(lo, ld, mk3(1.0f, 1.0f, 1.0f), p0);   // intersect(ray, bb), box centred at 0
+                if (ok) {
+                    m.p = p0;
+                    m.dir = ld;
+                    m.iter = 0;
+                    m.first = true;
+                    state = MARCH;
+                    break;
+                }
+            }
+            ++k;
+        }
+        if (__all(state == IDLE)) break;   // every lane idle => queue exhausted for this wave
+        // (3) far-field steps are a handful of flops: take them until a near-field evaluation is due
+        int result = 0;
+        float s = 0.0f;
+        if (state == MARCH) {
+            for (;;) {
+                s = norm(m.p) - 0.5f;
+                if (!(static_cast<double>(s) > 0.1)) break;   // `sdf_sphere > 0.1` compares against a double literal
+                result = march_step(m, s);
+                if (result) break;
+            }
+        }
+        // (4) near-field evaluation for the lanes that stopped at one
+        if (state == MARCH && result == 0) {
+            const float d2 = craterball_near(sc.noise, off, m.p, s);
+            result = march_step(m, d2);
+        }
+        // (5) finished marches fold into the ray's best hit and move on to the next primitive
+        if (state == MARCH && result != 0) {
+            if (result == 1) {
+                const PrimRec* pr = sc.prims + prim;
+                const f3 w = aff_pos(pr->fwd, m.p);
+                const float t = dot(w - o, d);
+                const unsigned long long key = make_key(t, prim);
+                if (key < best) {
+                    best = key;
+                    best_pos = w;
+                    improved = true;
+                    limit = fmaxf(t, 0.0f) * inv_len2 * 1.00001f + 1e-6f;
+                }
+            }
+            ++k;
+            state = SETUP;
+        }
+    }
+}
+
+// =============================================================================================
+// shade: Scene::trace's per-hit body (src/Scene.cpp:46-75) around Object::deflectRay
+// (src/Object.cpp:35-44) and BasicMaterial::deflect.  Survivors are appended to the next bounce's
+// queue with one atomic per wave (ballot + popcount prefix).
+// =============================================================================================
+__device__ __forceinline__ void wave_append(bool pred, uint32_t value, uint32_t* counter, uint32_t* queue) {
+    const unsigned long long m = __ballot(pred);
+    if (!pred) return;
+    const uint32_t lane = __lane_id();
+    const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+    uint32_t base = 0;
+    if (rank == 0) base = atomicAdd(counter, static_cast<uint32_t>(__popcll(m)));
+    base = __shfl(base, __ffsll(static_cast<long long>(m)) - 1);
+    queue[base + rank] = value;
+}
+
+// Applies one bounce to the path in `slot`; returns whether the path continues.
+__device__ __forceinline__ bool apply_bounce(const PathBuffers& pb, uint32_t slot, const PrimRegs& pr, f3 world_pos, const Bounce& b,
+                                             uint32_t bounce, uint32_t max_bounces) {
+    const f3 wdir = lin_mul(pr.fwd, b.dir);   // only the direction returns to world space (src/Object.cpp:42)
+    const f3 npos = mk3(world_pos.x + 1e-3f * wdir.x, world_pos.y + 1e-3f * wdir.y, world_pos.z + 1e-3f * wdir.z);   // src/Scene.cpp:54
+    float4 att = pb.att[slot];
+    float4 rad = pb.rad[slot];
+    rad.x += b.emitted.x * att.x;
+    rad.y += b.emitted.y * att.y;
+    rad.z += b.emitted.z * att.z;
+    att.x *= b.attenuation.x;
+    att.y *= b.attenuation.y;
+    att.z *= b.attenuation.z;
+    pb.rad[slot] = rad;
+    const bool alive = !(att.x + att.z + att.y < 1e-6f) && (bounce + 1 < max_bounces);   // r + b + g, src/Scene.cpp:73
+    if (alive) {
+        pb.att[slot] = att;
+        pb.ray_o[slot] = st4(npos);
+        pb.ray_d[slot] = st4(wdir);
+    }
+    return alive;
+}
+
+__global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce, uint32_t max_bounces) {
+    const uint32_t n = bounce == 0 ? bp.n_slots : pb.counters[bounce].n_live;
+    const uint32_t* queue = bounce == 0 ? nullptr : pb.queue[bounce & 1];
+    uint32_t* next_queue = pb.queue[(bounce + 1) & 1];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // all lanes of a wave run the same number of iterations so that the wave-wide ballots line up
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool alive = false, to_sdf = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = queue ? queue[i] : i;
+            const unsigned long long key = pb.hit_key[slot];
+            if (key != kMissKey) {
+                const uint32_t prim = static_cast<uint32_t>(key & 0xffffffffu);
+                PrimRegs pr;
+                load_prim(sc.prims, prim, pr);
+                if (pr.kind == 3u) {
+                    to_sdf = true;
+                } else {
+                    const f3 wp = ld3(pb.hit_pos[slot]);
+                    const f3 d = ld3(pb.ray_d[slot]);
+                    const f3 ld = lin_mul(pr.inv, d);
+                    const f3 lp = aff_pos(pr.inv, wp);
+                    f3 nrm;
+                    if (pr.kind == 0u) {
+                        nrm = unit(lp);   // Sphere::normal src/Geometry.cpp:43-45
+                    } else if (pr.kind == 1u) {
+                        nrm = rect_normal(lp, mk3(pr.p[0], pr.p[1], pr.p[2]));
+                    } else {   // Triangle::normal src/Geometry.cpp:18-20
+                        const f3 a = mk3(pr.p[0], pr.p[1], pr.p[2]), b = mk3(pr.p[3], pr.p[4], pr.p[5]);
+                        const f3 c = mk3(sc.tri_c[3 * prim], sc.tri_c[3 * prim + 1], sc.tri_c[3 * prim + 2]);
+                        nrm = unit(cross(b - a, c - a));
+                    }
+                    const uint32_t s_local = slot / bp.n_pix;
+                    Rng rng(bp.seed, slot - s_local * bp.n_pix, bp.first_sample + s_local, 1u + bounce);
+                    const Bounce b = deflect(sc.materials[pr.material], ld, nrm, rng);
+                    alive = apply_bounce(pb, slot, pr, wp, b, bounce, max_bounces);
+                }
+            }
+        }
+        wave_append(alive, slot, &pb.counters[bounce + 1].n_live, next_queue);
+        wave_append(to_sdf, slot, &pb.counters[bounce].n_sdf_shade, pb.sdf_shade_queue);
+    }
+}
+
+// SDF hits: the normal is a forward difference of four SDF evaluations (signedDistanceNormal,
+// include/Object.hpp:118-132); all four points lie in the near field of a hit.
+__global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce, uint32_t max_bounces) {
+    const uint32_t n = pb.counters[bounce].n_sdf_shade;
+    uint32_t* next_queue = pb.queue[(bounce + 1) & 1];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool alive = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = pb.sdf_shade_queue[i];
+            const uint32_t prim = static_cast<uint32_t>(pb.hit_key[slot] & 0xffffffffu);
+            PrimRegs pr;
+            load_prim(sc.prims, prim, pr);
+            const f3 wp = ld3(pb.hit_pos[slot]);
+            const f3 d = ld3(pb.ray_d[slot]);
+            const f3 ld = lin_mul(pr.inv, d);
+            const f3 lp = aff_pos(pr.inv, wp);
+            const f3 off = mk3(pr.p[0], pr.p[1], pr.p[2]);
+            const float delta = 1e-3f;
+            float v[4];
+#pragma unroll 1
+            for (int e = 0; e < 4; ++e) {
+                const f3 q = mk3(lp.x + (e == 1 ? delta : 0.0f), lp.y + (e == 2 ? delta : 0.0f), lp.z + (e == 3 ? delta : 0.0f));
+                const float s = norm(q) - 0.5f;
+                v[e] = (static_cast<double>(s) > 0.1) ? s : craterball_near(sc.noise, off, q, s);
+            }
+            const f3 g = mk3(v[1] - v[0], v[2] - v[0], v[3] - v[0]) * (1.0f / delta);
+            const f3 nrm = unit(g);
+            const uint32_t s_local = slot / bp.n_pix;
+            Rng rng(bp.seed, slot - s_local * bp.n_pix, bp.first_sample + s_local, 1u + bounce);
+            const Bounce b = deflect(sc.materials[pr.material], ld, nrm, rng);
+            alive = apply_bounce(pb, slot, pr, wp, b, bounce, max_bounces);
+        }
+        wave_append(alive, slot, &pb.counters[bounce + 1].n_live, next_queue);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.totals->sdf_shades, static_cast<unsigned long long>(n));
+}
+
+__global__ void k_finish_batch(PathBuffers pb, uint32_t bounces, uint32_t n_slots) {
+    unsigned long long rays = n_slots;
+    for (uint32_t b = 1; b < bounces; ++b) rays += pb.counters[b].n_live;
+    pb.totals->rays += rays;
+}
+
+// frame[pix] += sample 0 + sample 1 + ... of this batch, sequentially in sample order
+__global__ void __launch_bounds__(256) k_accumulate(BatchParams bp, PathBuffers pb, float* frame) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t samples = bp.n_slots / bp.n_pix;
+    for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < bp.n_pix; pix += stride) {
+        float r = frame[3 * pix], g = frame[3 * pix + 1], b = frame[3 * pix + 2];
+        for (uint32_t s = 0; s < samples; ++s) {
+            const float4 c = pb.rad[s * bp.n_pix + pix];
+            r += c.x;
+            g += c.y;
+            b += c.z;
+        }
+        frame[3 * pix] = r;
+        frame[3 * pix + 1] = g;
+        frame[3 * pix + 2] = b;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scale(const float* in, float k, size_t n, float* out) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i] * k;
+}
+
+__global__ void __launch_bounds__(256) k_load_rays(const float* pos, const float* dir, uint32_t n, PathBuffers pb) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pb.ray_o[i] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], 0.0f);
+    pb.ray_d[i] = make_float4(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2], 0.0f);
+    pb.att[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    pb.rad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+__global__ void __launch_bounds__(256) k_export_rad(PathBuffers pb, uint32_t n, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = pb.rad[i];
+    out[3 * i] = c.x;
+    out[3 * i + 1] = c.y;
+    out[3 * i + 2] = c.z;
+}
+
+// =============================================================================================
+// tone mappers (src/ToneMapper.cpp)
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_tonemap_filmic(const float* in, float* out, size_t n) {   // :53-72
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float p = in[i];
+        const float v = (p * (a * p + b)) / (p * (c * p + d) + e);
+        out[i] = fminf(fmaxf(v, 0.0f), 1.0f);
+    }
+}
+
+constexpr int kReinhardBlocks = 1024;
+
+// Pass 1 of ReinhardToneMapper :6-21: per-block partial sum of log(lum + 1e-6), min and max of the
+// luminance (which reads the blue channel twice, as the reference does).
+__global__ void __launch_bounds__(256) k_reinhard_reduce(const float* in, size_t n_pix, float* scratch) {
+    __shared__ float s_sum[256], s_min[256], s_max[256];
+    float sum = 0.0f, mn = 3.402823466e38f, mx = -3.402823466e38f;
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
+        const float lum = 0.27f * in[3 * i] + 0.67f * in[3 * i + 2] + 0.06f * in[3 * i + 2];
+        mn = fminf(mn, lum);
+        mx = fmaxf(mx, lum);
+        sum += logf(lum + 1e-6f);
+    }
+    s_sum[threadIdx.x] = sum;
+    s_min[threadIdx.x] = mn;
+    s_max[threadIdx.x] = mx;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) {
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + w];
+            s_min[threadIdx.x] = fminf(s_min[threadIdx.x], s_min[threadIdx.x + w]);
+            s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + w]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        scratch[3 * blockIdx.x] = s_sum[0];
+        scratch[3 * blockIdx.x + 1] = s_min[0];
+        scratch[3 * blockIdx.x + 2] = s_max[0];
+    }
+}
+
+// Pass 2: one block folds the partials and derives k = alpha / avgLum (:23-30).
+__global__ void __launch_bounds__(256) k_reinhard_key(float* scratch, int n_blocks, size_t n_pix) {
+    __shared__ double s_sum[256];
+    __shared__ float s_min[256], s_max[256];
+    double sum = 0.0;
+    float mn = 3.402823466e38f, mx = -3.402823466e38f;
+    for (int i = threadIdx.x; i < n_blocks; i += 256) {
+        sum += scratch[3 * i];
+        mn = fminf(mn, scratch[3 * i + 1]);
+        mx = fmaxf(mx, scratch[3 * i + 2]);
+    }
+    s_sum[threadIdx.x] = sum;
+    s_min[threadIdx.x] = mn;
+    s_max[threadIdx.x] = mx;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) {
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + w];
+            s_min[threadIdx.x] = fminf(s_min[threadIdx.x], s_min[threadIdx.x + w]);
+            s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + w]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float acc = static_cast<float>(s_sum[0]);
+        const float avg = expf(acc / static_cast<float>(n_pix));
+        const float log_avg = log2f(avg), log_min = log2f(s_min[0] + 1e-6f), log_max = log2f(s_max[0] + 1e-6f);
+        const float alpha = 0.18f * powf(4.0f, (2.0f * log_avg - log_min - log_max) / (log_max - log_min));
+        scratch[3 * n_blocks] = alpha / avg;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_reinhard_map(const float* in, float* out, size_t n, const float* key) {   // :34-49
+    const float k = *key;
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float sc = in[i] * k;
+        out[i] = sc / (1.0f + sc);
+    }
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+static inline uint32_t grid_for(size_t n, uint32_t cap = 256u * 32u) {
+    const size_t b = (n + 255) / 256;
+    return static_cast<uint32_t>(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+void launch_generate(hipStream_t st, const CameraRec& cam, const BatchParams& bp, const PathBuffers& pb) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(bp.n_slots)), dim3(256), 0, st, cam, bp, pb);
+}
+
+void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, int bvh_depth) {
+    const dim3 grid(grid_for(bp.n_slots, 256u * 16u)), block(256);
+    if (bvh_depth <= 8) hipLaunchKernelGGL(k_extend<8>, grid, block, 0, st, sc, bp, pb, bounce);
+    else if (bvh_depth <= 24) hipLaunchKernelGGL(k_extend<24>, grid, block, 0, st, sc, bp, pb, bounce);
+    else if (bvh_depth <= 40) hipLaunchKernelGGL(k_extend<40>, grid, block, 0, st, sc, bp, pb, bounce);
+    else hipLaunchKernelGGL(k_extend<64>, grid, block, 0, st, sc, bp, pb, bounce);
+}
+
+void launch_sdf_march(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce) {
+    // persistent waves: enough blocks to fill the chip a few times over, every wave drains the queue
+    hipLaunchKernelGGL(k_sdf_march, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce);
+}
+
+void launch_shade(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, uint32_t max_bounces) {
+    hipLaunchKernelGGL(k_shade, dim3(grid_for(bp.n_slots, 256u * 16u)), dim3(256), 0, st, sc, bp, pb, bounce, max_bounces);
+}
+
+void launch_shade_sdf(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, uint32_t max_bounces) {
+    hipLaunchKernelGGL(k_shade_sdf, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce, max_bounces);
+}
+
+void launch_finish_batch(hipStream_t st, const PathBuffers& pb, uint32_t bounces, uint32_t n_slots) {
+    hipLaunchKernelGGL(k_finish_batch, dim3(1), dim3(1), 0, st, pb, bounces, n_slots);
+}
+
+void launch_accumulate(hipStream_t st, const BatchParams& bp, const PathBuffers& pb, float* frame) {
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(bp.n_pix)), dim3(256), 0, st, bp, pb, frame);
+}
+
+void launch_scale(hipStream_t st, const float* in, float k, size_t n, float* out) {
+    hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(256), 0, st, in, k, n, out);
+}
+
+void launch_load_rays(hipStream_t st, const float* pos, const float* dir, uint32_t n, const PathBuffers& pb) {
+    hipLaunchKernelGGL(k_load_rays, dim3((n + 255) / 256), dim3(256), 0, st, pos, dir, n, pb);
+}
+
+void launch_export_rad(hipStream_t st, const PathBuffers& pb, uint32_t n, float* out) {
+    hipLaunchKernelGGL(k_export_rad, dim3((n + 255) / 256), dim3(256), 0, st, pb, n, out);
+}
+
+void launch_tonemap_filmic(hipStream_t st, const float* in, float* out, size_t n) {
+    hipLaunchKernelGGL(k_tonemap_filmic, dim3(grid_for(n)), dim3(256), 0, st, in, out, n);
+}
+
+size_t reinhard_scratch_floats() { return 3 * kReinhardBlocks + 4; }
+
+void launch_tonemap_reinhard(hipStream_t st, const float* in, float* out, size_t width, size_t height, float* scratch, size_t) {
+    const size_t n_pix = width * height;
+    const int blocks = static_cast<int>(grid_for(n_pix, kReinhardBlocks));
+    hipLaunchKernelGGL(k_reinhard_reduce, dim3(blocks), dim3(256), 0, st, in, n_pix, scratch);
+    hipLaunchKernelGGL(k_reinhard_key, dim3(1), dim3(256), 0, st, scratch, blocks, n_pix);
+    hipLaunchKernelGGL(k_reinhard_map, dim3(grid_for(3 * n_pix)), dim3(256), 0, st, in, out, 3 * n_pix, scratch + 3 * blocks);
+}
+
+}   // namespace mipt

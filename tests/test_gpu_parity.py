@@ -1,0 +1,211 @@
+"""HIP path (through the C ABI of libmipt.so) against the CPU restatement on the same inputs.
+
+Bars, per stage:
+  * analytic primitives (sphere, box, triangle): primary-hit primitive indices identical, hit distances
+    bit-identical (the exact part of the device code evaluates the reference's expressions in the
+    reference's order, without fused multiply-add);
+  * crater-ball SDF: the device evaluates the SDF with FMA contraction and hardware exp2/log2/rcp/rsq,
+    so marches may stop one step apart: at most 0.5 % of pixels may disagree on hit / miss, distances
+    agree to 2e-4 (the march's own stop tolerance is 1e-4);
+  * traced paths / rendered images with the shared counter-based random numbers: identical ray counts
+    on analytic scenes, radiance equal to 1e-4 relative on at least 99.5 % of paths (a path whose
+    rejection-sampling decision flips on a last-bit difference legitimately diverges).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases as G
+from pathtracer_amd import api, scene as S
+
+pytestmark = pytest.mark.gpu
+
+FIXTURE = os.path.join(os.path.dirname(__file__), "golden", "reference_cases.npz")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context()
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def alg():
+    return api.HostAlgebra()
+
+
+@pytest.fixture(scope="module")
+def golden():
+    z = np.load(FIXTURE, allow_pickle=False)
+    return {k[4:]: z[k] for k in z.files if k.startswith("out_")}
+
+
+def _unit(v):
+    return (v / np.linalg.norm(v, axis=-1, keepdims=True)).astype(np.float32)
+
+
+ANALYTIC = {
+    "sphere_box": (lambda a: G.sphere_box_scene(a), lambda a: G.parity_camera(a), 96, 96),
+    "mixed": (lambda a: G.mixed_scene(a), lambda a: G.parity_camera(a, 4.0 / 3.0), 96, 72),
+    "cornell": (lambda a: S.cornell_scene(a), lambda a: S.cornell_camera(a), 64, 64),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ANALYTIC))
+def test_primary_hits_analytic_exact(name, ctx, alg, oracle):
+    mk_scene, mk_cam, w, h = ANALYTIC[name]
+    flat, cam = mk_scene(alg), mk_cam(alg)
+    want_prim, want_t = oracle.scene(flat).primary_hits(cam, w, h)
+    got_prim, got_t = ctx.primary_hits(ctx.upload(flat), cam, w, h)
+    assert np.array_equal(want_prim, got_prim), f"{np.sum(want_prim != got_prim)} primitive indices differ"
+    assert np.array_equal(want_t, got_t), f"max |dt| = {np.abs(want_t - got_t).max()}"
+    assert (want_prim >= 0).sum() > 0.2 * w * h
+
+
+@pytest.mark.parametrize("case", ["sb", "mx", "cb"])
+def test_primary_hits_match_reference_fixture(case, ctx, alg, golden):
+    """The same maps as the reference's own Tree::hit produced them (committed fixture)."""
+    mk_scene, mk_cam, w, h = {"sb": ANALYTIC["sphere_box"], "mx": ANALYTIC["mixed"], "cb": ANALYTIC["cornell"]}[case]
+    flat, cam = mk_scene(alg), mk_cam(alg)
+    got_prim, got_t = ctx.primary_hits(ctx.upload(flat), cam, w, h)
+    assert np.array_equal(golden[case + "_primary_prim"], got_prim)
+    assert np.array_equal(golden[case + "_primary_t"], got_t)
+
+
+def test_primary_hits_large_analytic(ctx, alg, oracle):
+    """2,000 primitives at 256 x 256: exercises a deep BVH against the oracle's non-culling scan."""
+    flat = S.random_scene(alg, 2000, seed=3, radius_scale=4.0)
+    cam = S.random_scene_camera(alg, aspect=1.0)
+    want_prim, want_t = oracle.scene(flat).primary_hits(cam, 256, 256)
+    ds = ctx.upload(flat)
+    got_prim, got_t = ctx.primary_hits(ds, cam, 256, 256)
+    assert ds.info()["depth"] >= 8
+    assert np.array_equal(want_prim, got_prim)
+    assert np.array_equal(want_t, got_t)
+    assert (want_prim >= 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("close", [False, True])
+def test_primary_hits_demo_scene(close, ctx, alg, oracle, golden):
+    noise = golden["noise12"]
+    flat = S.demo_scene(alg, noise)
+    cam = G.demo_closeup_camera(alg) if close else S.demo_camera(alg)
+    w = h = 48 if close else 64
+    got_prim, got_t = ctx.primary_hits(ctx.upload(flat), cam, w, h)
+    want_prim = golden["demo_close_prim" if close else "demo_primary_prim"]
+    want_t = golden["demo_close_t" if close else "demo_primary_t"]
+    mismatch = (want_prim != got_prim).mean()
+    assert mismatch <= 0.005, f"{mismatch:.4f} of pixels disagree on hit / miss"
+    both = (want_prim >= 0) & (got_prim >= 0)
+    assert both.sum() > (400 if close else 20)
+    assert np.abs(want_t - got_t)[both].max() <= 2e-4
+
+
+def _random_rays(n, seed, extent, inner):
+    r = np.random.RandomState(seed)
+    o = r.uniform(-extent, extent, (n, 3)).astype(np.float32)
+    d = _unit(r.uniform(-inner, inner, (n, 3)) - o)
+    return o, d
+
+
+@pytest.mark.parametrize("name", sorted(ANALYTIC))
+def test_trace_rays_analytic(name, ctx, alg, oracle):
+    mk_scene = ANALYTIC[name][0]
+    flat = mk_scene(alg)
+    o, d = _random_rays(4000, 5, 6.0, 4.0)
+    want = oracle.scene(flat).trace(o, d, 8, rng_mode=1, seed=99)
+    got, prim, t = ctx.trace_rays(ctx.upload(flat), o, d, 8, seed=99, first_hit=True)
+    wp, wt, _ = oracle.scene(flat).closest_hit(o, d)
+    assert np.array_equal(wp, prim)
+    assert np.array_equal(wt[wp >= 0], t[wp >= 0])
+    close = np.all(np.abs(want - got) <= 1e-4 * np.maximum(1.0, np.abs(want)), axis=1)
+    assert close.mean() >= 0.995, f"only {close.mean():.4f} of paths agree"
+    assert want.max() > 0
+
+
+def test_trace_rays_demo_scene(ctx, alg, oracle, golden):
+    noise = golden["noise12"]
+    flat = S.demo_scene(alg, noise)
+    r = np.random.RandomState(8)
+    o = (np.array([0.0, 0.5, -2.0]) + _unit(r.normal(size=(1500, 3))) * 3.0).astype(np.float32)
+    d = _unit(np.array([0.0, 0.5, -2.0]) + r.uniform(-0.6, 0.6, (1500, 3)) - o)
+    osc = oracle.scene(flat)
+    want = osc.trace(o, d, 8, rng_mode=1, seed=4)
+    got, prim, t = ctx.trace_rays(ctx.upload(flat), o, d, 8, seed=4, first_hit=True)
+    wp, wt, _ = osc.closest_hit(o, d)
+    assert (wp != prim).mean() <= 0.01
+    both = (wp >= 0) & (prim >= 0)
+    assert both.sum() > 500
+    assert np.abs(wt - t)[both].max() <= 2e-4
+    # radiance: same random numbers, slightly different normals -> compare in aggregate and per path loosely
+    assert abs(want.mean() - got.mean()) <= 0.03 * want.mean()
+    close = np.all(np.abs(want - got) <= 0.02 + 0.02 * np.abs(want), axis=1)
+    assert close.mean() >= 0.97
+
+
+@pytest.mark.parametrize("name", sorted(ANALYTIC))
+def test_render_matches_oracle_with_shared_random_numbers(name, ctx, alg, oracle):
+    mk_scene, mk_cam, w, h = ANALYTIC[name]
+    flat, cam = mk_scene(alg), mk_cam(alg)
+    w, h = w // 2, h // 2
+    want, wstats = oracle.scene(flat).render(cam, w, h, 6, 8, rng_mode=1, seed=7, threads=0, full_width=True)
+    got, gstats = ctx.render(ctx.upload(flat), cam, w, h, 6, 8, seed=7)
+    assert gstats["paths"] == wstats["paths"] == w * h * 8
+    assert abs(gstats["rays"] - wstats["rays"]) <= 2e-3 * wstats["rays"]
+    close = np.abs(want - got) <= 1e-4 * np.maximum(1.0, np.abs(want))
+    assert close.all(axis=2).mean() >= 0.99
+    assert abs(want.mean() - got.mean()) <= 2e-3 * want.mean()
+
+
+def test_render_sample_sharding_is_consistent(ctx, alg):
+    """Samples [0,8) rendered at once equal samples [0,4) + [4,8) rendered separately (what two GPUs
+    would compute), up to the order of float additions."""
+    flat, cam = S.cornell_scene(alg), S.cornell_camera(alg)
+    ds = ctx.upload(flat)
+    full, _ = ctx.render(ds, cam, 40, 40, 8, 8, seed=3)
+    a, _ = ctx.render(ds, cam, 40, 40, 8, 4, seed=3, first_sample=0)
+    b, _ = ctx.render(ds, cam, 40, 40, 8, 4, seed=3, first_sample=4)
+    assert np.allclose(full, 0.5 * (a + b), rtol=1e-5, atol=1e-6)
+    again, _ = ctx.render(ds, cam, 40, 40, 8, 8, seed=3)
+    assert np.array_equal(full, again), "renders must be bitwise reproducible"
+
+
+def test_render_demo_scene_matches_oracle(ctx, alg, oracle, golden):
+    noise = golden["noise12"]
+    flat = S.demo_scene(alg, noise)
+    cam = G.demo_closeup_camera(alg)
+    want, wstats = oracle.scene(flat).render(cam, 32, 32, 8, 4, rng_mode=1, seed=11, threads=0, full_width=True)
+    got, gstats = ctx.render(ctx.upload(flat), cam, 32, 32, 8, 4, seed=11)
+    assert gstats["paths"] == wstats["paths"]
+    assert abs(gstats["rays"] - wstats["rays"]) <= 0.01 * wstats["rays"]
+    assert abs(want.mean() - got.mean()) <= 0.03 * want.mean()
+    rmse = np.sqrt(np.mean((want - got) ** 2))
+    assert rmse <= 0.05 * max(want.mean(), 1e-3) * 4, rmse
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_tonemap(kind, ctx, oracle, golden):
+    z = np.load(FIXTURE, allow_pickle=False)
+    hdr = z["in_hdr"]
+    got = ctx.tonemap(kind, hdr)
+    want = golden["tonemap_reinhard" if kind == 0 else "tonemap_filmic"]
+    if kind == 1:
+        assert np.array_equal(want, got)
+    else:   # the log-average is a parallel reduction: rounding differs from the sequential float sum
+        assert np.allclose(want, got, rtol=2e-5, atol=1e-7)
+    big = np.random.RandomState(2).gamma(0.5, 2.0, (270, 480, 3)).astype(np.float32)
+    assert np.allclose(oracle.tonemap(kind, big), ctx.tonemap(kind, big), rtol=5e-5, atol=1e-7)
+
+
+def test_cancel_and_errors(ctx, alg):
+    flat, cam = S.cornell_scene(alg), S.cornell_camera(alg)
+    ds = ctx.upload(flat)
+    with pytest.raises(api.MiptError):
+        ctx.render(ds, cam, 1, 40, 8, 1)          # W - 1 == 0 divides by zero in the reference
+    with pytest.raises(api.MiptError):
+        ctx.render(ds, cam, 40, 40, 0, 1)
+    ctx.cancel()                                   # a cancel before the call is cleared by the call
+    img, st = ctx.render(ds, cam, 16, 16, 4, 2)
+    assert st["paths"] == 16 * 16 * 2 and img.max() > 0
