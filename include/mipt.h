@@ -92,8 +92,25 @@ typedef struct {
     uint64_t rays;           /* closest-hit queries (Tree::hit equivalents) */
     uint64_t sdf_rays;       /* rays that entered an SDF primitive's bounding box */
     uint64_t sdf_shades;     /* hits shaded on an SDF primitive (4 SDF evaluations each) */
+    /* work done by the SDF march: evaluations answered by the far-field early-out
+     * (PathTracerDemo.cpp:364-366), evaluations that ran the near-field body, and the noise() calls
+     * (PathTracerDemo.cpp:56-70) those made */
+    uint64_t sdf_far_evals;
+    uint64_t sdf_near_evals;
+    uint64_t sdf_noise_calls;
+    /* the same for the normals of SDF hits (4 evaluations per shaded hit) */
+    uint64_t shade_evals;
+    uint64_t shade_noise_calls;
     double   ms_device;      /* stream time of the call, HIP events */
+    /* Per-stage stream time and launch counts, filled only while mipt_set_profiling(ctx, 1) is in
+     * force (an event pair brackets every launch): generate, extend, sdf_march, shade, shade_sdf,
+     * accumulate. */
+    double   stage_ms[6];
+    uint64_t stage_launches[6];
 } mipt_stats;
+
+enum { MIPT_STAGE_GENERATE = 0, MIPT_STAGE_EXTEND = 1, MIPT_STAGE_SDF_MARCH = 2, MIPT_STAGE_SHADE = 3,
+       MIPT_STAGE_SHADE_SDF = 4, MIPT_STAGE_ACCUMULATE = 5 };
 
 /* ---- context ------------------------------------------------------------------------------ */
 /* Renderer::Renderer / startThreadPool (src/Renderer.cpp:9-35): binds a GPU instead of starting
@@ -106,6 +123,9 @@ void mipt_shutdown(mipt_ctx*);
  * running render call stops at the next sample batch and returns MIPT_ERR_CANCELLED. */
 int  mipt_cancel(mipt_ctx*);
 int  mipt_last_hip_error(const mipt_ctx*);
+/* Measurement aid (no counterpart in the reference): when on, render calls bracket every kernel launch
+ * with HIP events on the context's stream and report per-stage times in mipt_stats. */
+int  mipt_set_profiling(mipt_ctx*, int on);
 const char* mipt_strerror(int status);
 
 /* ---- scene -------------------------------------------------------------------------------- */

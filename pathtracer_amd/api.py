@@ -11,6 +11,9 @@ from . import capi
 from .capi import MiptError, check, f32, fp   # noqa: F401
 
 
+STAGES = ("generate", "extend", "sdf_march", "shade", "shade_sdf", "accumulate")
+
+
 class HostAlgebra:
     """rotation / affine_mul / affine_inverse / noise_transform in the reference's operation order."""
 
@@ -107,6 +110,9 @@ class Context:
     def upload(self, flat):
         return DeviceScene(self, flat)
 
+    def set_profiling(self, on):
+        check(capi.dll().mipt_set_profiling(self.h, 1 if on else 0), "mipt_set_profiling")
+
     def cancel(self):
         check(capi.dll().mipt_cancel(self.h), "mipt_cancel")
 
@@ -117,7 +123,11 @@ class Context:
     @staticmethod
     def _stats(st):
         return dict(paths=int(st.paths), rays=int(st.rays), sdf_rays=int(st.sdf_rays), sdf_shades=int(st.sdf_shades),
-                    ms_device=float(st.ms_device))
+                    sdf_far_evals=int(st.sdf_far_evals), sdf_near_evals=int(st.sdf_near_evals),
+                    sdf_noise_calls=int(st.sdf_noise_calls), shade_evals=int(st.shade_evals),
+                    shade_noise_calls=int(st.shade_noise_calls), ms_device=float(st.ms_device),
+                    stage_ms=dict(zip(STAGES, (float(x) for x in st.stage_ms))),
+                    stage_launches=dict(zip(STAGES, (int(x) for x in st.stage_launches))))
 
     def render(self, scene, cam16, w, h, bounces, spp, seed=1, first_sample=0, flags=0):
         """Renderer::render: (h, w, 3) float32 mean image and the call's statistics."""

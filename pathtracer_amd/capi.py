@@ -42,11 +42,13 @@ class Settings(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("sdf_rays", C.c_uint64), ("sdf_shades", C.c_uint64),
-                ("ms_device", C.c_double)]
+                ("sdf_far_evals", C.c_uint64), ("sdf_near_evals", C.c_uint64), ("sdf_noise_calls", C.c_uint64),
+                ("shade_evals", C.c_uint64), ("shade_noise_calls", C.c_uint64),
+                ("ms_device", C.c_double), ("stage_ms", C.c_double * 6), ("stage_launches", C.c_uint64 * 6)]
 
 
 EXPORTS = [
-    "mipt_init", "mipt_shutdown", "mipt_cancel", "mipt_last_hip_error", "mipt_strerror", "mipt_scene_upload",
+    "mipt_init", "mipt_shutdown", "mipt_cancel", "mipt_last_hip_error", "mipt_set_profiling", "mipt_strerror", "mipt_scene_upload",
     "mipt_scene_free", "mipt_scene_info", "mipt_render", "mipt_render_accumulate", "mipt_scale_device",
     "mipt_primary_hits", "mipt_trace_rays", "mipt_tonemap", "mipt_tonemap_device", "mipt_affine_inverse",
     "mipt_rotation", "mipt_affine_mul", "mipt_noise_transform", "mipt_world_bounds",
@@ -68,6 +70,7 @@ def dll():
         d.mipt_shutdown.restype = None
         d.mipt_cancel.argtypes = [C.c_void_p]
         d.mipt_last_hip_error.argtypes = [C.c_void_p]
+        d.mipt_set_profiling.argtypes = [C.c_void_p, C.c_int]
         d.mipt_scene_upload.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         d.mipt_scene_free.argtypes = [C.c_void_p]
         d.mipt_scene_free.restype = None

@@ -38,16 +38,24 @@ struct mipt_ctx {
     float* stage = nullptr;          // staging for probes / host tone mapping
     size_t stage_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // optional per-launch timing
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    struct Span { int stage; size_t e0, e1; };
+    std::vector<Span> spans;
+    size_t ev_used = 0;
 };
 
 struct mipt_scene {
-    mipt_ctx* ctx = nullptr;
+    int device = 0;
     SceneDev dev{};
     void* d_prims = nullptr;
     void* d_tri = nullptr;
     void* d_mats = nullptr;
     void* d_nodes = nullptr;
     void* d_sdf = nullptr;
+    void* d_oct = nullptr;
     uint32_t n_nodes = 0, n_analytic = 0, n_sdf = 0;
     int depth = 0;
 };
@@ -148,13 +156,42 @@ CameraRec pack_camera(const mipt_camera& cam) {
     return r;
 }
 
+// Brackets one launch with an event pair when profiling is on.
+struct StageTimer {
+    mipt_ctx* c;
+    int stage;
+    size_t e0 = 0;
+    bool on;
+    static size_t next_event(mipt_ctx* c) {
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return size_t(-1);
+            c->ev_pool.push_back(e);
+        }
+        return c->ev_used++;
+    }
+    StageTimer(mipt_ctx* ctx, int st) : c(ctx), stage(st), on(ctx->profiling) {
+        if (!on) return;
+        e0 = next_event(c);
+        if (e0 == size_t(-1)) { on = false; return; }
+        (void)hipEventRecord(c->ev_pool[e0], c->stream);
+    }
+    ~StageTimer() {
+        if (!on) return;
+        const size_t e1 = next_event(c);
+        if (e1 == size_t(-1)) return;
+        (void)hipEventRecord(c->ev_pool[e1], c->stream);
+        c->spans.push_back({stage, e0, e1});
+    }
+};
+
 // One sample batch: generate (or preloaded rays) -> bounce loop.  Leaves per-path radiance in pb.rad.
 void enqueue_bounces(mipt_ctx* c, const mipt_scene* sc, const BatchParams& bp, uint32_t bounces) {
     for (uint32_t b = 0; b < bounces; ++b) {
-        launch_extend(c->stream, sc->dev, bp, c->pb, b, sc->depth);
-        if (sc->n_sdf) launch_sdf_march(c->stream, sc->dev, bp, c->pb, b);
-        launch_shade(c->stream, sc->dev, bp, c->pb, b, bounces);
-        if (sc->n_sdf) launch_shade_sdf(c->stream, sc->dev, bp, c->pb, b, bounces);
+        { StageTimer t(c, MIPT_STAGE_EXTEND); launch_extend(c->stream, sc->dev, bp, c->pb, b, sc->depth); }
+        if (sc->n_sdf) { StageTimer t(c, MIPT_STAGE_SDF_MARCH); launch_sdf_march(c->stream, sc->dev, bp, c->pb, b); }
+        { StageTimer t(c, MIPT_STAGE_SHADE); launch_shade(c->stream, sc->dev, bp, c->pb, b, bounces); }
+        if (sc->n_sdf) { StageTimer t(c, MIPT_STAGE_SHADE_SDF); launch_shade_sdf(c->stream, sc->dev, bp, c->pb, b, bounces); }
     }
     launch_finish_batch(c->stream, c->pb, bounces, bp.n_slots);
 }
@@ -175,6 +212,8 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
     if (rc != MIPT_OK) return rc;
     const CameraRec cr = pack_camera(*cam);
     HIP_TRY(c, hipMemsetAsync(c->pb.totals, 0, sizeof(Totals), c->stream));
+    c->ev_used = 0;
+    c->spans.clear();
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     uint32_t done = 0;
     int status = MIPT_OK;
@@ -193,9 +232,9 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.flags = st->flags;
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
-        launch_generate(c->stream, cr, bp, c->pb);
+        { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate(c->stream, cr, bp, c->pb); }
         enqueue_bounces(c, sc, bp, st->bounces);
-        launch_accumulate(c->stream, bp, c->pb, d_sum);
+        { StageTimer t(c, MIPT_STAGE_ACCUMULATE); launch_accumulate(c->stream, bp, c->pb, d_sum); }
         done += now;
         // keep at most a couple of batches queued so that cancellation stays responsive
         if (done < st->spp) HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -212,7 +251,23 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         stats->rays = t.rays;
         stats->sdf_rays = t.sdf_rays;
         stats->sdf_shades = t.sdf_shades;
+        stats->sdf_far_evals = t.sdf_far_evals;
+        stats->sdf_near_evals = t.sdf_near_evals;
+        stats->sdf_noise_calls = t.sdf_noise_calls;
+        stats->shade_evals = t.shade_near_evals;
+        stats->shade_noise_calls = t.shade_noise_calls;
         stats->ms_device = ms;
+        for (int k = 0; k < 6; ++k) {
+            stats->stage_ms[k] = 0.0;
+            stats->stage_launches[k] = 0;
+        }
+        for (const auto& sp : c->spans) {
+            float d = 0.0f;
+            if (hipEventElapsedTime(&d, c->ev_pool[sp.e0], c->ev_pool[sp.e1]) == hipSuccess) {
+                stats->stage_ms[sp.stage] += d;
+                stats->stage_launches[sp.stage] += 1;
+            }
+        }
     }
     return status;
 }
@@ -262,6 +317,7 @@ void mipt_shutdown(mipt_ctx* c) {
     if (c->tm_scratch) (void)hipFree(c->tm_scratch);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -273,6 +329,13 @@ int mipt_cancel(mipt_ctx* c) {
 }
 
 int mipt_last_hip_error(const mipt_ctx* c) { return c ? c->last_hip : 0; }
+
+int mipt_set_profiling(mipt_ctx* c, int on) {
+    if (!c) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    c->profiling = on != 0;
+    return MIPT_OK;
+}
 
 const char* mipt_strerror(int s) {
     switch (s) {
@@ -362,7 +425,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
 
     auto* s = new (std::nothrow) mipt_scene;
     if (!s) return MIPT_ERR_OUT_OF_MEMORY;
-    s->ctx = c;
+    s->device = c->device;
     auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
         if (bytes == 0) return hipSuccess;
         hipError_t e = hipMalloc(dst, bytes);
@@ -374,6 +437,33 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     if (e == hipSuccess) e = upload(&s->d_mats, mats.data(), mats.size() * sizeof(MaterialRec));
     if (e == hipSuccess) e = upload(&s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode));
     if (e == hipSuccess) e = upload(&s->d_sdf, sdf.data(), sdf.size() * sizeof(SdfBox));
+    // noise() (PathTracerDemo.cpp:56-70) applies the transform T = (L, t), samples, scales by 1.1 and
+    // repeats; octave i therefore samples q_i = A_i p + b_i with A_0 = L, b_0 = t, A_i = 1.1 L A_{i-1},
+    // b_i = 1.1 L b_{i-1} + t.  Composed in double, stored as float, so the 8 octaves of one call can be
+    // evaluated side by side.
+    float oct[8 * 13] = {};
+    if (any_sdf) {
+        const float* nt = d->noise_transform;
+        double A[9], bb[3];
+        for (int i = 0; i < 9; ++i) A[i] = nt[i];
+        for (int i = 0; i < 3; ++i) bb[i] = nt[9 + i];
+        float kf = 0.02f;
+        for (int o = 0; o < 8; ++o) {
+            for (int i = 0; i < 9; ++i) oct[13 * o + i] = static_cast<float>(A[i]);
+            for (int i = 0; i < 3; ++i) oct[13 * o + 9 + i] = static_cast<float>(bb[i]);
+            oct[13 * o + 12] = kf;
+            kf *= 0.9f;
+            double A2[9], b2[3];
+            for (int r = 0; r < 3; ++r) {
+                for (int cidx = 0; cidx < 3; ++cidx)
+                    A2[3 * r + cidx] = 1.1f * (nt[3 * r] * A[cidx] + nt[3 * r + 1] * A[3 + cidx] + nt[3 * r + 2] * A[6 + cidx]);
+                b2[r] = 1.1f * (nt[3 * r] * bb[0] + nt[3 * r + 1] * bb[1] + nt[3 * r + 2] * bb[2]) + nt[9 + r];
+            }
+            std::memcpy(A, A2, sizeof(A));
+            std::memcpy(bb, b2, sizeof(bb));
+        }
+        if (e == hipSuccess) e = upload(&s->d_oct, oct, sizeof(oct));
+    }
     if (e != hipSuccess) {
         c->last_hip = static_cast<int>(e);
         mipt_scene_free(s);
@@ -384,6 +474,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     s->dev.materials = static_cast<const MaterialRec*>(s->d_mats);
     s->dev.nodes = static_cast<const BvhNode*>(s->d_nodes);
     s->dev.sdf_boxes = static_cast<const SdfBox*>(s->d_sdf);
+    s->dev.noise_oct = static_cast<const float*>(s->d_oct);
     s->dev.n_sdf = static_cast<uint32_t>(sdf.size());
     s->dev.n_prims = n;
     if (d->noise_transform) std::memcpy(s->dev.noise, d->noise_transform, sizeof(float) * 12);
@@ -398,11 +489,9 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
 
 void mipt_scene_free(mipt_scene* s) {
     if (!s) return;
-    if (s->ctx) {
-        (void)hipSetDevice(s->ctx->device);
-        (void)hipStreamSynchronize(s->ctx->stream);
-    }
-    for (void* p : {s->d_prims, s->d_tri, s->d_mats, s->d_nodes, s->d_sdf})
+    // hipFree waits for work that still uses the memory; the context may already be gone
+    (void)hipSetDevice(s->device);
+    for (void* p : {s->d_prims, s->d_tri, s->d_mats, s->d_nodes, s->d_sdf, s->d_oct})
         if (p) (void)hipFree(p);
     delete s;
 }

@@ -58,7 +58,10 @@ struct SceneDev {
     const SdfBox* sdf_boxes;
     uint32_t n_sdf;
     uint32_t n_prims;
-    float noise[12];
+    float noise[12];               // the demo's noiseTransform(): Linear row-major, then the translation
+    // noise() unrolled: octave i samples A_i p + b_i with weight k_i; 13 floats per octave (A row-major,
+    // b, k), 8 octaves (null when the scene has no SDF primitive)
+    const float* noise_oct;
 };
 
 // Per-bounce queue counters of one sample batch, zeroed once per batch.
@@ -70,7 +73,9 @@ struct BounceCounters {
 };
 
 struct Totals {
-    unsigned long long rays, sdf_rays, sdf_shades, pad;
+    unsigned long long rays, sdf_rays, sdf_shades;
+    unsigned long long sdf_far_evals, sdf_near_evals, sdf_noise_calls;   // sdf_march: SDF evaluations by kind, noise() calls
+    unsigned long long shade_near_evals, shade_noise_calls;              // shade_sdf: the same for the normals
 };
 
 constexpr int kMaxBounces = 64;

@@ -444,31 +444,48 @@ __device__ __forceinline__ float fast_tanh(float c) {
     return 1.0f - 2.0f * fast_rcp(e + 1.0f);
 }
 
-// noise() :56-70.  triangle(x) = -1 + 4 |x - 0.25 - floor(x + 0.25)| = 4 |fract(x + 0.25) - 0.5| - 1, so
-// the octave sum is 4 * sum_i k_i (a_x + a_y + a_z) - 3 * sum_i k_i with a = |fract(. + 0.25) - 0.5|.
-// The per-octave `location *= 1.1` is folded into the next octave's matrix.
-__device__ __forceinline__ float fbm_noise(const float (&T)[12], f3 p) {
-    float acc = 0.0f;
-    float k = 0.02f;
-    float x = fmaf(T[0], p.x, fmaf(T[1], p.y, fmaf(T[2], p.z, T[9])));
-    float y = fmaf(T[3], p.x, fmaf(T[4], p.y, fmaf(T[5], p.z, T[10])));
-    float z = fmaf(T[6], p.x, fmaf(T[7], p.y, fmaf(T[8], p.z, T[11])));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float ax = fabsf(__builtin_amdgcn_fractf(x + 0.25f) - 0.5f);
-        const float ay = fabsf(__builtin_amdgcn_fractf(y + 0.25f) - 0.5f);
-        const float az = fabsf(__builtin_amdgcn_fractf(z + 0.25f) - 0.5f);
-        acc = fmaf(k, (ax + ay) + az, acc);
-        k *= 0.9f;
-        if (i < 7) {
-            const float sx = 1.1f * x, sy = 1.1f * y, sz = 1.1f * z;
-            x = fmaf(T[0], sx, fmaf(T[1], sy, fmaf(T[2], sz, T[9])));
-            y = fmaf(T[3], sx, fmaf(T[4], sy, fmaf(T[5], sz, T[10])));
-            z = fmaf(T[6], sx, fmaf(T[7], sy, fmaf(T[8], sz, T[11])));
-        }
-    }
-    // sum_i 0.02 * 0.9^i, i < 8
-    return 4.0f * acc - 3.0f * 0.11390656f;
+// ---- wave-wide reductions on the DPP crossbar (every lane must be active) --------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float identity, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t identity, uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(identity), static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kRowHalfMirror = 0x141, kRowMirror = 0x140, kRowBcast15 = 0x142, kRowBcast31 = 0x143;
+constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114;
+
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f<kQuadXor1>(0.0f, v);
+    v += dpp_f<kQuadXor2>(0.0f, v);
+    v += dpp_f<kRowHalfMirror>(0.0f, v);
+    v += dpp_f<kRowMirror>(0.0f, v);
+    v += dpp_f<kRowBcast15, 0xa>(0.0f, v);
+    v += dpp_f<kRowBcast31, 0xc>(0.0f, v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    const float ninf = -3.402823466e38f;
+    v = fmaxf(v, dpp_f<kQuadXor1>(ninf, v));
+    v = fmaxf(v, dpp_f<kQuadXor2>(ninf, v));
+    v = fmaxf(v, dpp_f<kRowHalfMirror>(ninf, v));
+    v = fmaxf(v, dpp_f<kRowMirror>(ninf, v));
+    v = fmaxf(v, dpp_f<kRowBcast15, 0xa>(ninf, v));
+    v = fmaxf(v, dpp_f<kRowBcast31, 0xc>(ninf, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ uint32_t wave_min_u(uint32_t v) {
+    v = min(v, dpp_u<kQuadXor1>(0xffffffffu, v));
+    v = min(v, dpp_u<kQuadXor2>(0xffffffffu, v));
+    v = min(v, dpp_u<kRowHalfMirror>(0xffffffffu, v));
+    v = min(v, dpp_u<kRowMirror>(0xffffffffu, v));
+    v = min(v, dpp_u<kRowBcast15, 0xa>(0xffffffffu, v));
+    v = min(v, dpp_u<kRowBcast31, 0xc>(0xffffffffu, v));
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+__device__ __forceinline__ float bcast_lane(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
 // One cell of for_each_nearby_scattered_point :79-116: hashed, jittered lattice point.  The reference
@@ -497,111 +514,173 @@ __device__ __forceinline__ bool project_cell(f3 point, f3 off, float scale, f3& 
     return norm_sq(on_sphere - point) < 0.1f;
 }
 
+// What each lane contributes to a wave-cooperative SDF evaluation.
+struct CoopLane {
+    float bi, bj, bk;     // this lane's cell of the 4^3 big-crater neighbourhood (-1..2 per axis)
+    float si, sj, sk;     // lanes 0-7 / 8-15: cell of the 2^3 small / tiny-crater neighbourhood (0..1)
+    float A[9], b[3], k;  // noise octave (lane & 7): q = A p + b is the point the octave samples, k its weight
+};
+constexpr int kCoopPts = 136;               // 2 * 64 fallout points + 2 final points, rounded up to 8
+constexpr int kCoopLdsFloats = 4 * kCoopPts;   // x, y, z, value
+
+__device__ __forceinline__ CoopLane make_coop_lane(const float* noise_oct, uint32_t lane) {
+    CoopLane c;
+    c.bi = static_cast<float>(static_cast<int>(lane >> 4) - 1);
+    c.bj = static_cast<float>(static_cast<int>((lane >> 2) & 3u) - 1);
+    c.bk = static_cast<float>(static_cast<int>(lane & 3u) - 1);
+    c.si = static_cast<float>((lane >> 2) & 1u);
+    c.sj = static_cast<float>((lane >> 1) & 1u);
+    c.sk = static_cast<float>(lane & 1u);
+    const float* o = noise_oct + 13 * (lane & 7u);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.A[i] = o[i];
+    c.b[0] = o[9];
+    c.b[1] = o[10];
+    c.b[2] = o[11];
+    c.k = o[12];
+    return c;
+}
+
 // CraterBallObject::signedDistance :361-466 for a point whose sphere distance s = |pos| - 0.5 is
-// already known to be <= 0.1 (the far field returns s itself).
-__device__ __forceinline__ float craterball_near(const float (&NT)[12], f3 off, f3 pos, float s) {
+// already known to be <= 0.1 (the far field returns s itself), evaluated by ONE WAVE for ONE point:
+// off, pos and s are wave-uniform and every lane must be active.
+//
+//   * the 64 cells of the big-crater neighbourhood map to the 64 lanes;
+//   * noise() calls -- two per big-crater cell that deposits fallout, two for the final terms -- are
+//     cut into their 8 octaves and spread over the wave as (point, octave) tasks: octave i samples
+//     A_i p + b_i with the composed affine held per lane, so the octaves of a call run side by side
+//     instead of one after another, and a DPP sum over 8 lanes returns the call's value;
+//   * the 8 small-crater and 8 tiny-crater cells run on lanes 0-15; the order dependence of the small
+//     craters through min_age is an exclusive prefix minimum over those lanes.
+//
+// A single evaluation therefore costs a few hundred wave instructions with no data-dependent loop
+// except the fallout rounds, instead of ~13,000 lane instructions in a divergent loop; the 256-step
+// worst case of a march is ~0.3 ms instead of ~10 ms.  Sums are tree reductions, so values differ
+// from a sequential evaluation by rounding only.
+//
+// pow(0, y) = 0 for the y in [1, 3] that occurs, so a cell whose linear falloff is zero adds exactly
+// nothing to the fallout and its two noise() calls are skipped.
+__device__ __forceinline__ float coop_near(const CoopLane& cl, float* lds, f3 off, f3 pos, float s, uint32_t lane, uint32_t& noise_calls) {
+    float* px = lds;
+    float* py = lds + kCoopPts;
+    float* pz = lds + 2 * kCoopPts;
+    float* pv = lds + 3 * kCoopPts;
     const float il = fast_rsq(norm_sq(pos));
     const f3 u = mk3(-pos.x * il, -pos.y * il, -pos.z * il);
-    float crater = 0.0f, tiny = 0.0f, fallout = 0.0f;
-    uint32_t min_age = 0xffffu;   // ages are compared as their 16-bit integers (age = bits / 65535)
 
-    {   // big craters :375-409 -- 4^3 cells.  Pass 1 marks the cells inside the shell in a 64-bit mask;
-        // pass 2 visits the marked cells in the reference's order, so the loop trip count of a wave is
-        // the largest popcount among its lanes rather than 64.
-        const float scale = 2.0f;
-        const f3 query = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
-        const f3 origin = mk3(floorf(query.x), floorf(query.y), floorf(query.z));
-        unsigned long long mask = 0ull;
-        for (int c = 0; c < 64; ++c) {
-            const f3 g = mk3(origin.x + static_cast<float>((c >> 4) - 1), origin.y + static_cast<float>(((c >> 2) & 3) - 1),
-                             origin.z + static_cast<float>((c & 3) - 1));
-            uint32_t hash;
-            const f3 point = scattered_cell(g, 0.3f, hash);
-            f3 on;
-            if (project_cell(point, off, scale, on)) mask |= 1ull << c;
-        }
-        while (mask) {
-            const int c = __ffsll(static_cast<long long>(mask)) - 1;
-            mask &= mask - 1ull;
-            const f3 g = mk3(origin.x + static_cast<float>((c >> 4) - 1), origin.y + static_cast<float>(((c >> 2) & 3) - 1),
-                             origin.z + static_cast<float>((c & 3) - 1));
-            uint32_t hash;
-            const f3 point = scattered_cell(g, 0.3f, hash);
-            f3 on;
-            project_cell(point, off, scale, on);
-            const float t = static_cast<float>(hash & 0xffffu) * (1.0f / 65535.0f);
-            const float size = fmaf(0.4f * t, t, 0.05f);
-            const f3 qv = query - on;
-            const float dist2 = norm_sq(qv);
-            const float dist = dist2 * fast_rsq(fmaxf(dist2, 1e-30f));
-            const float c20 = 20.0f * (dist - size);
-            float depth = fast_tanh(c20);
-            if (c20 > 1e-3f) depth = 0.9f * t * depth * fast_rcp(0.02f * fast_rcp(c20) + c20 * c20);
-            crater = fmaf(-0.02f, depth, crater);
-            if (dist >= size) {
-                // pow(0, y) = 0 for the y in [1, 3] that occurs here, so a zero linear falloff adds
-                // exactly nothing and both noise calls can be skipped
-                const float lin = fmaxf(0.0f, 1.2f - dist * fast_rcp(size * 5.0f));
-                if (lin > 0.0f) {
-                    const float idist = fast_rsq(fmaxf(dist2, 1e-30f));
-                    const f3 dirv = mk3(qv.x * idist, qv.y * idist, qv.z * idist);
-                    const float n1 = fbm_noise(NT, mk3(fmaf(3.0f * size, dirv.x, on.x), fmaf(3.0f * size, dirv.y, on.y), fmaf(3.0f * size, dirv.z, on.z)));
-                    const float n2 = fbm_noise(NT, mk3(fmaf(40.0f * size, dirv.x, on.x), fmaf(40.0f * size, dirv.y, on.y), fmaf(40.0f * size, dirv.z, on.z)));
-                    const float falloff = fast_exp2((2.0f + 3.0f * n1) * fast_log2(lin));
-                    fallout = fmaf(0.1f * falloff * (0.2f + 0.4f * depth), n2, fallout);
-                }
-            } else {
-                min_age = min(min_age, hash >> 16);
-            }
-        }
+    // ---- big craters :375-409, one cell per lane -------------------------------------------
+    const f3 query = mk3(fmaf(u.x, 2.0f, off.x), fmaf(u.y, 2.0f, off.y), fmaf(u.z, 2.0f, off.z));
+    uint32_t hash;
+    f3 on;
+    const f3 point = scattered_cell(mk3(floorf(query.x) + cl.bi, floorf(query.y) + cl.bj, floorf(query.z) + cl.bk), 0.3f, hash);
+    const bool pass = project_cell(point, off, 2.0f, on);
+    const float t = static_cast<float>(hash & 0xffffu) * (1.0f / 65535.0f);
+    const float size = fmaf(0.4f * t, t, 0.05f);
+    const f3 qv = query - on;
+    const float dist2 = norm_sq(qv);
+    const float idist = fast_rsq(fmaxf(dist2, 1e-30f));
+    const float dist = dist2 * idist;
+    const float c20 = 20.0f * (dist - size);
+    float depth = fast_tanh(c20);
+    if (c20 > 1e-3f) depth = 0.9f * t * depth * fast_rcp(0.02f * fast_rcp(c20) + c20 * c20);
+    const bool outside = dist >= size;
+    const float lin = fmaxf(0.0f, 1.2f - dist * fast_rcp(size * 5.0f));
+    const bool deposits = pass && outside && lin > 0.0f;
+    const float crater_big = wave_sum(pass ? -0.02f * depth : 0.0f);
+    // ages are compared as their 16-bit integers (age = bits / 65535); 0xffff is the initial 1.0
+    const uint32_t min_age0 = wave_min_u((pass && !outside) ? (hash >> 16) : 0xffffu);
+
+    // ---- noise() calls as (point, octave) tasks ---------------------------------------------
+    const unsigned long long dmask = __ballot(deposits);
+    const uint32_t n_dep = __popcll(dmask);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(dmask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(dmask), 0u));
+    if (deposits) {
+        const float k1 = 3.0f * size * idist, k2 = 40.0f * size * idist;
+        px[2 * rank] = fmaf(k1, qv.x, on.x);
+        py[2 * rank] = fmaf(k1, qv.y, on.y);
+        pz[2 * rank] = fmaf(k1, qv.z, on.z);
+        px[2 * rank + 1] = fmaf(k2, qv.x, on.x);
+        py[2 * rank + 1] = fmaf(k2, qv.y, on.y);
+        pz[2 * rank + 1] = fmaf(k2, qv.z, on.z);
     }
-    {   // small craters :412-437 -- 2^3 cells, order matters through min_age
-        const float scale = 10.0f;
-        const f3 query = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
-        const f3 origin = mk3(floorf(query.x), floorf(query.y), floorf(query.z));
-#pragma unroll 1
-        for (int c = 0; c < 8; ++c) {
-            const f3 g = mk3(origin.x + static_cast<float>(c >> 2), origin.y + static_cast<float>((c >> 1) & 1), origin.z + static_cast<float>(c & 1));
-            uint32_t hash;
-            const f3 point = scattered_cell(g, 0.5f, hash);
-            const uint32_t age = hash >> 16;
-            if (age > min_age) continue;
-            f3 on;
-            if (!project_cell(point, off, scale, on)) continue;
-            const float t = static_cast<float>(hash & 0xffffu) * (1.0f / 65535.0f);
-            const float size = fmaf(0.35f * t, t, 0.05f);
-            const float dist = sqrtf(norm_sq(query - on));
-            const float c50 = 50.0f * (dist - size);
-            if (c50 < 0.0f) {
-                min_age = min(min_age, age);
-                crater = fmaxf(-0.005f * fast_tanh(c50), crater);
-            }
-        }
+    const uint32_t n_pts = 2u * n_dep + 2u;
+    if (lane < 2u) {
+        const float f = lane == 0u ? 20.0f : 1.5f;
+        px[2 * n_dep + lane] = (pos.x + off.x) * f;
+        py[2 * n_dep + lane] = (pos.y + off.y) * f;
+        pz[2 * n_dep + lane] = (pos.z + off.z) * f;
     }
-    {   // tiny craters :440-463
-        const float scale = 60.0f;
-        const f3 query = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
-        const f3 origin = mk3(floorf(query.x), floorf(query.y), floorf(query.z));
-#pragma unroll 1
-        for (int c = 0; c < 8; ++c) {
-            const f3 g = mk3(origin.x + static_cast<float>(c >> 2), origin.y + static_cast<float>((c >> 1) & 1), origin.z + static_cast<float>(c & 1));
-            uint32_t hash;
-            const f3 point = scattered_cell(g, 0.5f, hash);
-            f3 on;
-            if (!project_cell(point, off, scale, on)) continue;
-            if ((hash >> 16) > min_age) continue;
-            const float t = static_cast<float>(hash & 0xffffu) * (1.0f / 65535.0f);
-            const float size = fmaf(0.35f, t, 0.02f);
-            const float dist = sqrtf(norm_sq(query - on));
-            tiny = fmaxf(-0.004f * size * (-0.5f + 0.5f * fast_tanh(50.0f * (dist - size))), tiny);
-        }
+    noise_calls = n_pts;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < n_pts; base += 8u) {
+        const uint32_t slot = base + (lane >> 3);
+        const float x = px[slot], y = py[slot], z = pz[slot];   // slots past n_pts hold stale but finite data
+        const float qx = fmaf(cl.A[0], x, fmaf(cl.A[1], y, fmaf(cl.A[2], z, cl.b[0])));
+        const float qy = fmaf(cl.A[3], x, fmaf(cl.A[4], y, fmaf(cl.A[5], z, cl.b[1])));
+        const float qz = fmaf(cl.A[6], x, fmaf(cl.A[7], y, fmaf(cl.A[8], z, cl.b[2])));
+        // triangle(v) = -1 + 4 |v - 0.25 - floor(v + 0.25)| = 4 |fract(v + 0.25) - 0.5| - 1  (:26-28)
+        const float a = (fabsf(__builtin_amdgcn_fractf(qx + 0.25f) - 0.5f) + fabsf(__builtin_amdgcn_fractf(qy + 0.25f) - 0.5f)) +
+                        fabsf(__builtin_amdgcn_fractf(qz + 0.25f) - 0.5f);
+        float v = cl.k * a;
+        v += dpp_f<kQuadXor1>(0.0f, v);
+        v += dpp_f<kQuadXor2>(0.0f, v);
+        v += dpp_f<kRowHalfMirror>(0.0f, v);
+        // noise = sum_i k_i (4 a_i - 3) with sum_i k_i = 0.02 (1 - 0.9^8) / 0.1
+        if ((lane & 7u) == 0u) pv[slot] = fmaf(4.0f, v, -3.0f * 0.11390656f);
     }
-    const f3 q = pos + off;
-    return s + crater + tiny + fallout + 0.01f * fbm_noise(NT, mk3(q.x * 20.0f, q.y * 20.0f, q.z * 20.0f)) +
-           0.4f * fbm_noise(NT, mk3(q.x * 1.5f, q.y * 1.5f, q.z * 1.5f));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float fallout_c = 0.0f;
+    if (deposits) {
+        const float n1 = pv[2 * rank], n2 = pv[2 * rank + 1];
+        const float falloff = fast_exp2((2.0f + 3.0f * n1) * fast_log2(lin));
+        fallout_c = 0.1f * falloff * (0.2f + 0.4f * depth) * n2;
+    }
+    const float fallout = wave_sum(fallout_c);
+    const float nf1 = pv[2 * n_dep], nf2 = pv[2 * n_dep + 1];
+
+    // ---- small craters :412-437 on lanes 0-7, tiny craters :440-463 on lanes 8-15 ------------
+    const bool is_small = lane < 8u, is_tiny = (lane >> 3) == 1u;
+    const float scale = is_small ? 10.0f : 60.0f;
+    const f3 q2 = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
+    uint32_t h2;
+    f3 on2;
+    const f3 pt2 = scattered_cell(mk3(floorf(q2.x) + cl.si, floorf(q2.y) + cl.sj, floorf(q2.z) + cl.sk), 0.5f, h2);
+    const bool pass2 = project_cell(pt2, off, scale, on2);
+    const float t2 = static_cast<float>(h2 & 0xffffu) * (1.0f / 65535.0f);
+    const uint32_t age2 = h2 >> 16;
+    const float d2 = sqrtf(norm_sq(q2 - on2));
+    const float size2 = is_small ? fmaf(0.35f * t2, t2, 0.05f) : fmaf(0.35f, t2, 0.02f);
+    const float c50 = 50.0f * (d2 - size2);
+    const float th = fast_tanh(c50);
+    // A small-crater cell takes effect iff it passes the shell and rim tests and its age does not exceed
+    // the running minimum, which only cells that took effect lower: the running minimum before cell k is
+    // min(min_age0, ages of the earlier candidates), an exclusive prefix minimum over lanes 0-7.
+    const bool cand = is_small && pass2 && c50 < 0.0f && age2 <= min_age0;
+    const uint32_t xa = cand ? age2 : 0xffffffffu;
+    uint32_t incl = xa;
+    incl = min(incl, dpp_u<kRowShr1>(0xffffffffu, incl));
+    incl = min(incl, dpp_u<kRowShr2>(0xffffffffu, incl));
+    incl = min(incl, dpp_u<kRowShr4>(0xffffffffu, incl));
+    const uint32_t excl = dpp_u<kRowShr1>(0xffffffffu, incl);
+    const bool takes = cand && age2 <= excl;
+    const float crater_small = wave_max(takes ? -0.005f * th : -3.402823466e38f);
+    const uint32_t min_age1 = min(min_age0, wave_min_u(xa));
+    const bool tiny_ok = is_tiny && pass2 && age2 <= min_age1;
+    const float tiny = wave_max(tiny_ok ? -0.004f * size2 * (-0.5f + 0.5f * th) : 0.0f);
+    const float crater = fmaxf(crater_big, crater_small);
+    return s + crater + tiny + fallout + 0.01f * nf1 + 0.4f * nf2;
 }
 
 #pragma clang fp contract(off)
+
+// Adds a per-lane counter into a 64-bit total with one atomic per wave.
+__device__ __forceinline__ void wave_add_total(unsigned long long* total, uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (__lane_id() == 0 && v) atomicAdd(total, static_cast<unsigned long long>(v));
+}
 
 // =============================================================================================
 // sdf_march: SDFObjectCRTP::hitLocalRay (include/Object.hpp:135-167) as a per-lane state machine.
@@ -650,6 +729,11 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
     float inv_len2 = 0.0f, limit = 0.0f;
     unsigned long long best = kMissKey;
     bool improved = false;
+    uint32_t c_far = 0, c_near = 0, c_noise = 0;
+    __shared__ float s_coop[4 * kCoopLdsFloats];
+    const uint32_t lane = __lane_id();
+    float* lds = s_coop + (threadIdx.x >> 6) * kCoopLdsFloats;
+    const CoopLane cl = make_coop_lane(sc.noise_oct, lane);
     March m;
     m.p = m.dir = mk3(0, 0, 0);
     m.d = 0.0f;
@@ -722,15 +806,30 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
             for (;;) {
                 s = norm(m.p) - 0.5f;
                 if (!(static_cast<double>(s) > 0.1)) break;   // `sdf_sphere > 0.1` compares against a double literal
+                ++c_far;
                 result = march_step(m, s);
                 if (result) break;
             }
         }
-        // (4) near-field evaluation for the lanes that stopped at one
-        if (state == MARCH && result == 0) {
-            const float d2 = craterball_near(sc.noise, off, m.p, s);
-            result = march_step(m, d2);
+        // (4) near-field evaluations: the wave serves its lanes' requests one after another, all 64
+        // lanes working on one point at a time
+        const bool wants = state == MARCH && result == 0;
+        unsigned long long need = __ballot(wants);
+        float d2 = 0.0f;
+        while (need) {
+            const int src = __ffsll(static_cast<long long>(need)) - 1;
+            need &= need - 1ull;
+            const f3 P = mk3(bcast_lane(m.p.x, src), bcast_lane(m.p.y, src), bcast_lane(m.p.z, src));
+            const f3 O = mk3(bcast_lane(off.x, src), bcast_lane(off.y, src), bcast_lane(off.z, src));
+            uint32_t calls;
+            const float val = coop_near(cl, lds, O, P, bcast_lane(s, src), lane, calls);
+            if (lane == static_cast<uint32_t>(src)) {
+                d2 = val;
+                c_noise += calls;
+                ++c_near;
+            }
         }
+        if (wants) result = march_step(m, d2);
         // (5) finished marches fold into the ray's best hit and move on to the next primitive
         if (state == MARCH && result != 0) {
             if (result == 1) {
@@ -749,6 +848,9 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
             state = SETUP;
         }
     }
+    wave_add_total(&pb.totals->sdf_far_evals, c_far);
+    wave_add_total(&pb.totals->sdf_near_evals, c_near);
+    wave_add_total(&pb.totals->sdf_noise_calls, c_noise);
 }
 
 // =============================================================================================
@@ -844,28 +946,55 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
     uint32_t* next_queue = pb.queue[(bounce + 1) & 1];
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounds = (n + stride - 1) / stride;
+    uint32_t c_far = 0, c_near = 0, c_noise = 0;
+    __shared__ float s_coop[4 * kCoopLdsFloats];
+    const uint32_t lane = __lane_id();
+    float* lds = s_coop + (threadIdx.x >> 6) * kCoopLdsFloats;
+    const CoopLane cl = make_coop_lane(sc.noise_oct, lane);
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        bool alive = false;
+        const bool valid = i < n;
         uint32_t slot = 0;
-        if (i < n) {
+        PrimRegs pr;
+        f3 wp = mk3(0, 0, 0), ld = mk3(0, 0, 0), lp = mk3(0, 0, 0), off = mk3(0, 0, 0);
+        if (valid) {
             slot = pb.sdf_shade_queue[i];
             const uint32_t prim = static_cast<uint32_t>(pb.hit_key[slot] & 0xffffffffu);
-            PrimRegs pr;
             load_prim(sc.prims, prim, pr);
-            const f3 wp = ld3(pb.hit_pos[slot]);
+            wp = ld3(pb.hit_pos[slot]);
             const f3 d = ld3(pb.ray_d[slot]);
-            const f3 ld = lin_mul(pr.inv, d);
-            const f3 lp = aff_pos(pr.inv, wp);
-            const f3 off = mk3(pr.p[0], pr.p[1], pr.p[2]);
-            const float delta = 1e-3f;
-            float v[4];
-#pragma unroll 1
+            ld = lin_mul(pr.inv, d);
+            lp = aff_pos(pr.inv, wp);
+            off = mk3(pr.p[0], pr.p[1], pr.p[2]);
+        }
+        // four SDF values per hit: at the hit and at +delta along x, y, z; the wave evaluates them one
+        // point at a time
+        const float delta = 1e-3f;
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        unsigned long long need = __ballot(valid);
+        while (need) {
+            const int src = __ffsll(static_cast<long long>(need)) - 1;
+            need &= need - 1ull;
+            const f3 P = mk3(bcast_lane(lp.x, src), bcast_lane(lp.y, src), bcast_lane(lp.z, src));
+            const f3 O = mk3(bcast_lane(off.x, src), bcast_lane(off.y, src), bcast_lane(off.z, src));
+#pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const f3 q = mk3(lp.x + (e == 1 ? delta : 0.0f), lp.y + (e == 2 ? delta : 0.0f), lp.z + (e == 3 ? delta : 0.0f));
+                const f3 q = mk3(P.x + (e == 1 ? delta : 0.0f), P.y + (e == 2 ? delta : 0.0f), P.z + (e == 3 ? delta : 0.0f));
                 const float s = norm(q) - 0.5f;
-                v[e] = (static_cast<double>(s) > 0.1) ? s : craterball_near(sc.noise, off, q, s);
+                float val = s;
+                uint32_t calls = 0;
+                const bool far = static_cast<double>(s) > 0.1;   // wave-uniform: q is
+                if (!far) val = coop_near(cl, lds, O, q, s, lane, calls);
+                if (lane == static_cast<uint32_t>(src)) {
+                    v[e] = val;
+                    c_noise += calls;
+                    if (far) ++c_far;
+                    else ++c_near;
+                }
             }
+        }
+        bool alive = false;
+        if (valid) {
             const f3 g = mk3(v[1] - v[0], v[2] - v[0], v[3] - v[0]) * (1.0f / delta);
             const f3 nrm = unit(g);
             const uint32_t s_local = slot / bp.n_pix;
@@ -876,6 +1005,10 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
         wave_append(alive, slot, &pb.counters[bounce + 1].n_live, next_queue);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.totals->sdf_shades, static_cast<unsigned long long>(n));
+    if (rounds) {
+        wave_add_total(&pb.totals->shade_near_evals, c_near + c_far);
+        wave_add_total(&pb.totals->shade_noise_calls, c_noise);
+    }
 }
 
 __global__ void k_finish_batch(PathBuffers pb, uint32_t bounces, uint32_t n_slots) {
