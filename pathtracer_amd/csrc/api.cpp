@@ -74,8 +74,10 @@ namespace {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 size_t batch_path_budget() {
-    // paths in flight per sample batch; the per-slot state is 96 bytes plus 16 bytes of queues
-    size_t budget = size_t(32) << 20;
+    // Paths in flight per sample batch; the per-slot state is 88 bytes plus 16 bytes of queues, so the
+    // default working set is ~14 GB of the 288 GB.  Large batches matter: every bounce of every batch
+    // ends in a latency-bound tail (the longest SDF march), and fewer batches mean fewer tails.
+    size_t budget = size_t(128) << 20;
     if (const char* e = std::getenv("MIPT_BATCH_PATHS")) {
         const long long v = std::atoll(e);
         if (v > 0) budget = static_cast<size_t>(v);

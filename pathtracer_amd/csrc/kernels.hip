@@ -491,12 +491,14 @@ __device__ __forceinline__ float bcast_lane(float v, int lane) {
 // One cell of for_each_nearby_scattered_point :79-116: hashed, jittered lattice point.  The reference
 // forms the jitter through double; fmaf(scatter/2, m, g) rounds the same exact value once.
 __device__ __forceinline__ f3 scattered_cell(f3 g, float half_scatter, uint32_t& hash) {
-    uint32_t h = static_cast<uint32_t>(static_cast<int>(g.x)) * 885889u + static_cast<uint32_t>(static_cast<int>(g.y)) * 745273u +
-                 static_cast<uint32_t>(static_cast<int>(g.z)) * 1220689u;
+    // lattice coordinates and multipliers fit 24 signed bits, so the full-rate 24-bit multiply returns
+    // the same low 32 bits as the wrapping int multiply of the reference; h * 31 = (h << 5) - h
+    uint32_t h = static_cast<uint32_t>(__mul24(static_cast<int>(g.x), 885889)) + static_cast<uint32_t>(__mul24(static_cast<int>(g.y), 745273)) +
+                 static_cast<uint32_t>(__mul24(static_cast<int>(g.z), 1220689));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         h |= (h & 0x0f0f0f0fu) << 4;
-        h *= 31u;
+        h = (h << 5) - h;
     }
     hash = h;
     const float mx = static_cast<float>(h & 0x3ffu) * (1.0f / 512.0f) - 1.0f;
@@ -740,9 +742,13 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
     m.iter = 0;
     m.first = m.sign = false;
 
+    // When rays are scarce, spread them over the waves instead of letting the first waves take 64 each:
+    // a wave serves its lanes' near-field evaluations one after another, so rays per wave is latency.
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t quota = min(64u, (n + n_waves - 1) / n_waves);
     for (;;) {
         // (1) idle lanes fetch a ray
-        if (state == IDLE && !exhausted) {
+        if (state == IDLE && !exhausted && lane < quota) {
             const uint32_t i = atomicAdd(head, 1u);
             if (i < n) {
                 slot = pb.sdf_queue[i];
@@ -798,7 +804,8 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
             }
             ++k;
         }
-        if (__all(state == IDLE)) break;   // every lane idle => queue exhausted for this wave
+        // leave only when no lane holds a ray and no lane may fetch another one
+        if (__all(state == IDLE && (exhausted || lane >= quota))) break;
         // (3) far-field steps are a handful of flops: take them until a near-field evaluation is due
         int result = 0;
         float s = 0.0f;
@@ -951,8 +958,12 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
     const uint32_t lane = __lane_id();
     float* lds = s_coop + (threadIdx.x >> 6) * kCoopLdsFloats;
     const CoopLane cl = make_coop_lane(sc.noise_oct, lane);
+    // entries are dealt to waves round-robin (wave w, lane l takes entry w + l * n_waves) so that a short
+    // queue spreads over all waves: each wave evaluates its lanes' four points one after another
+    const uint32_t n_waves = stride >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const uint32_t i = r * stride + wave + lane * n_waves;
         const bool valid = i < n;
         uint32_t slot = 0;
         PrimRegs pr;
