@@ -522,8 +522,9 @@ struct CoopLane {
     float si, sj, sk;     // lanes 0-7 / 8-15: cell of the 2^3 small / tiny-crater neighbourhood (0..1)
     float A[9], b[3], k;  // noise octave (lane & 7): q = A p + b is the point the octave samples, k its weight
 };
-constexpr int kCoopPts = 136;               // 2 * 64 fallout points + 2 final points, rounded up to 8
-constexpr int kCoopLdsFloats = 4 * kCoopPts;   // x, y, z, value
+constexpr int kCoopGroup = 4;                                    // points one wave evaluates together
+constexpr int kCoopPts = 2 * 64 * kCoopGroup + 2 * kCoopGroup;   // fallout points + final points (a multiple of 8)
+constexpr int kCoopLdsFloats = 4 * kCoopPts;                     // x, y, z, value
 
 __device__ __forceinline__ CoopLane make_coop_lane(const float* noise_oct, uint32_t lane) {
     CoopLane c;
@@ -543,80 +544,118 @@ __device__ __forceinline__ CoopLane make_coop_lane(const float* noise_oct, uint3
     return c;
 }
 
-// CraterBallObject::signedDistance :361-466 for a point whose sphere distance s = |pos| - 0.5 is
-// already known to be <= 0.1 (the far field returns s itself), evaluated by ONE WAVE for ONE point:
-// off, pos and s are wave-uniform and every lane must be active.
+// row-wise (16 lanes) reductions: afterwards every lane of a row holds the row's result
+__device__ __forceinline__ float row_max(float v) {
+    const float ninf = -3.402823466e38f;
+    v = fmaxf(v, dpp_f<kQuadXor1>(ninf, v));
+    v = fmaxf(v, dpp_f<kQuadXor2>(ninf, v));
+    v = fmaxf(v, dpp_f<kRowHalfMirror>(ninf, v));
+    v = fmaxf(v, dpp_f<kRowMirror>(ninf, v));
+    return v;
+}
+__device__ __forceinline__ uint32_t row_min_u(uint32_t v) {
+    v = min(v, dpp_u<kQuadXor1>(0xffffffffu, v));
+    v = min(v, dpp_u<kQuadXor2>(0xffffffffu, v));
+    v = min(v, dpp_u<kRowHalfMirror>(0xffffffffu, v));
+    v = min(v, dpp_u<kRowMirror>(0xffffffffu, v));
+    return v;
+}
+
+// CraterBallObject::signedDistance :361-466 for G points (G = 1 or 4) whose sphere distances
+// s = |pos| - 0.5 are already known to be <= 0.1 (the far field returns s itself), evaluated by ONE
+// WAVE: off, pos and s are wave-uniform and every lane must be active.
 //
-//   * the 64 cells of the big-crater neighbourhood map to the 64 lanes;
+//   * the 64 cells of a point's big-crater neighbourhood map to the 64 lanes (one pass per point);
 //   * noise() calls -- two per big-crater cell that deposits fallout, two for the final terms -- are
 //     cut into their 8 octaves and spread over the wave as (point, octave) tasks: octave i samples
 //     A_i p + b_i with the composed affine held per lane, so the octaves of a call run side by side
-//     instead of one after another, and a DPP sum over 8 lanes returns the call's value;
-//   * the 8 small-crater and 8 tiny-crater cells run on lanes 0-15; the order dependence of the small
-//     craters through min_age is an exclusive prefix minimum over those lanes.
+//     instead of one after another, and a DPP sum over 8 lanes returns the call's value; the calls
+//     of all G points share the rounds;
+//   * the 8 small-crater and 8 tiny-crater cells of point g run on the 16 lanes of DPP row g; the
+//     order dependence of the small craters through min_age is an exclusive prefix minimum.
 //
-// A single evaluation therefore costs a few hundred wave instructions with no data-dependent loop
-// except the fallout rounds, instead of ~13,000 lane instructions in a divergent loop; the 256-step
-// worst case of a march is ~0.3 ms instead of ~10 ms.  Sums are tree reductions, so values differ
-// from a sequential evaluation by rounding only.
+// An evaluation costs a few hundred wave instructions with no data-dependent loop except the noise
+// rounds, instead of ~13,000 lane instructions in a divergent loop, so the 256-step worst case of a
+// march is a fraction of a millisecond.  Sums are tree reductions: values differ from a sequential
+// evaluation by rounding only, and a point's value does not depend on G or on its companions.
 //
 // pow(0, y) = 0 for the y in [1, 3] that occurs, so a cell whose linear falloff is zero adds exactly
 // nothing to the fallout and its two noise() calls are skipped.
-__device__ __forceinline__ float coop_near(const CoopLane& cl, float* lds, f3 off, f3 pos, float s, uint32_t lane, uint32_t& noise_calls) {
+template <int G>
+__device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, const f3 (&off)[G], const f3 (&pos)[G], const float (&s)[G],
+                                          uint32_t lane, float (&out)[G], uint32_t (&noise_calls)[G]) {
+    static_assert(G == 1 || G == kCoopGroup, "one point or a full group");
     float* px = lds;
     float* py = lds + kCoopPts;
     float* pz = lds + 2 * kCoopPts;
     float* pv = lds + 3 * kCoopPts;
-    const float il = fast_rsq(norm_sq(pos));
-    const f3 u = mk3(-pos.x * il, -pos.y * il, -pos.z * il);
+    f3 u[G];
+    float depth[G], lin[G], crater_big[G];
+    uint32_t rank[G], min_age0[G], base[G], n_dep[G];
+    bool deposits[G];
+    uint32_t n_fall = 0;   // fallout points staged so far
 
-    // ---- big craters :375-409, one cell per lane -------------------------------------------
-    const f3 query = mk3(fmaf(u.x, 2.0f, off.x), fmaf(u.y, 2.0f, off.y), fmaf(u.z, 2.0f, off.z));
-    uint32_t hash;
-    f3 on;
-    const f3 point = scattered_cell(mk3(floorf(query.x) + cl.bi, floorf(query.y) + cl.bj, floorf(query.z) + cl.bk), 0.3f, hash);
-    const bool pass = project_cell(point, off, 2.0f, on);
-    const float t = static_cast<float>(hash & 0xffffu) * (1.0f / 65535.0f);
-    const float size = fmaf(0.4f * t, t, 0.05f);
-    const f3 qv = query - on;
-    const float dist2 = norm_sq(qv);
-    const float idist = fast_rsq(fmaxf(dist2, 1e-30f));
-    const float dist = dist2 * idist;
-    const float c20 = 20.0f * (dist - size);
-    float depth = fast_tanh(c20);
-    if (c20 > 1e-3f) depth = 0.9f * t * depth * fast_rcp(0.02f * fast_rcp(c20) + c20 * c20);
-    const bool outside = dist >= size;
-    const float lin = fmaxf(0.0f, 1.2f - dist * fast_rcp(size * 5.0f));
-    const bool deposits = pass && outside && lin > 0.0f;
-    const float crater_big = wave_sum(pass ? -0.02f * depth : 0.0f);
-    // ages are compared as their 16-bit integers (age = bits / 65535); 0xffff is the initial 1.0
-    const uint32_t min_age0 = wave_min_u((pass && !outside) ? (hash >> 16) : 0xffffu);
-
-    // ---- noise() calls as (point, octave) tasks ---------------------------------------------
-    const unsigned long long dmask = __ballot(deposits);
-    const uint32_t n_dep = __popcll(dmask);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(dmask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(dmask), 0u));
-    if (deposits) {
-        const float k1 = 3.0f * size * idist, k2 = 40.0f * size * idist;
-        px[2 * rank] = fmaf(k1, qv.x, on.x);
-        py[2 * rank] = fmaf(k1, qv.y, on.y);
-        pz[2 * rank] = fmaf(k1, qv.z, on.z);
-        px[2 * rank + 1] = fmaf(k2, qv.x, on.x);
-        py[2 * rank + 1] = fmaf(k2, qv.y, on.y);
-        pz[2 * rank + 1] = fmaf(k2, qv.z, on.z);
+    // ---- big craters :375-409: one cell per lane, one pass per point -------------------------
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float il = fast_rsq(norm_sq(pos[g]));
+        u[g] = mk3(-pos[g].x * il, -pos[g].y * il, -pos[g].z * il);
+        const f3 query = mk3(fmaf(u[g].x, 2.0f, off[g].x), fmaf(u[g].y, 2.0f, off[g].y), fmaf(u[g].z, 2.0f, off[g].z));
+        uint32_t hash;
+        f3 on;
+        const f3 point = scattered_cell(mk3(floorf(query.x) + cl.bi, floorf(query.y) + cl.bj, floorf(query.z) + cl.bk), 0.3f, hash);
+        const bool pass = project_cell(point, off[g], 2.0f, on);
+        const float t = static_cast<float>(hash & 0xffffu) * (1.0f / 65535.0f);
+        const float size = fmaf(0.4f * t, t, 0.05f);
+        const f3 qv = query - on;
+        const float dist2 = norm_sq(qv);
+        const float idist = fast_rsq(fmaxf(dist2, 1e-30f));
+        const float dist = dist2 * idist;
+        const float c20 = 20.0f * (dist - size);
+        float dp = fast_tanh(c20);
+        if (c20 > 1e-3f) dp = 0.9f * t * dp * fast_rcp(0.02f * fast_rcp(c20) + c20 * c20);
+        depth[g] = dp;
+        const bool outside = dist >= size;
+        lin[g] = fmaxf(0.0f, 1.2f - dist * fast_rcp(size * 5.0f));
+        deposits[g] = pass && outside && lin[g] > 0.0f;
+        crater_big[g] = wave_sum(pass ? -0.02f * dp : 0.0f);
+        // ages are compared as their 16-bit integers (age = bits / 65535); 0xffff is the initial 1.0
+        min_age0[g] = wave_min_u((pass && !outside) ? (hash >> 16) : 0xffffu);
+        // stage this point's fallout noise() arguments
+        const unsigned long long dmask = __ballot(deposits[g]);
+        n_dep[g] = __popcll(dmask);
+        base[g] = n_fall;
+        rank[g] = n_fall + 2u * __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(dmask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(dmask), 0u));
+        n_fall += 2u * n_dep[g];
+        if (deposits[g]) {
+            const float k1 = 3.0f * size * idist, k2 = 40.0f * size * idist;
+            px[rank[g]] = fmaf(k1, qv.x, on.x);
+            py[rank[g]] = fmaf(k1, qv.y, on.y);
+            pz[rank[g]] = fmaf(k1, qv.z, on.z);
+            px[rank[g] + 1] = fmaf(k2, qv.x, on.x);
+            py[rank[g] + 1] = fmaf(k2, qv.y, on.y);
+            pz[rank[g] + 1] = fmaf(k2, qv.z, on.z);
+        }
+        noise_calls[g] = 2u * n_dep[g] + 2u;
     }
-    const uint32_t n_pts = 2u * n_dep + 2u;
-    if (lane < 2u) {
-        const float f = lane == 0u ? 20.0f : 1.5f;
-        px[2 * n_dep + lane] = (pos.x + off.x) * f;
-        py[2 * n_dep + lane] = (pos.y + off.y) * f;
-        pz[2 * n_dep + lane] = (pos.z + off.z) * f;
+    // the two final noise() arguments of every point follow the fallout points
+    const uint32_t n_pts = n_fall + 2u * G;
+    if (lane < 2u * G) {
+        f3 q = pos[0] + off[0];
+#pragma unroll
+        for (int g = 1; g < G; ++g)
+            if ((lane >> 1) == static_cast<uint32_t>(g)) q = pos[g] + off[g];
+        const float f = (lane & 1u) ? 1.5f : 20.0f;
+        px[n_fall + lane] = q.x * f;
+        py[n_fall + lane] = q.y * f;
+        pz[n_fall + lane] = q.z * f;
     }
-    noise_calls = n_pts;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t base = 0; base < n_pts; base += 8u) {
-        const uint32_t slot = base + (lane >> 3);
+
+    // ---- noise() :56-70 as (point, octave) tasks: 8 points per round ---------------------------
+    for (uint32_t first = 0; first < n_pts; first += 8u) {
+        const uint32_t slot = first + (lane >> 3);
         const float x = px[slot], y = py[slot], z = pz[slot];   // slots past n_pts hold stale but finite data
         const float qx = fmaf(cl.A[0], x, fmaf(cl.A[1], y, fmaf(cl.A[2], z, cl.b[0])));
         const float qy = fmaf(cl.A[3], x, fmaf(cl.A[4], y, fmaf(cl.A[5], z, cl.b[1])));
@@ -633,33 +672,36 @@ __device__ __forceinline__ float coop_near(const CoopLane& cl, float* lds, f3 of
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    float fallout_c = 0.0f;
-    if (deposits) {
-        const float n1 = pv[2 * rank], n2 = pv[2 * rank + 1];
-        const float falloff = fast_exp2((2.0f + 3.0f * n1) * fast_log2(lin));
-        fallout_c = 0.1f * falloff * (0.2f + 0.4f * depth) * n2;
-    }
-    const float fallout = wave_sum(fallout_c);
-    const float nf1 = pv[2 * n_dep], nf2 = pv[2 * n_dep + 1];
 
-    // ---- small craters :412-437 on lanes 0-7, tiny craters :440-463 on lanes 8-15 ------------
-    const bool is_small = lane < 8u, is_tiny = (lane >> 3) == 1u;
-    const float scale = is_small ? 10.0f : 60.0f;
-    const f3 q2 = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
+    // ---- small craters :412-437 on lanes 0-7 and tiny craters :440-463 on lanes 8-15 of row g ----
+    const uint32_t row = lane >> 4;
+    f3 ur = u[0], offr = off[0];
+    uint32_t min_age_r = min_age0[0];
+#pragma unroll
+    for (int g = 1; g < G; ++g)
+        if (row == static_cast<uint32_t>(g)) {
+            ur = u[g];
+            offr = off[g];
+            min_age_r = min_age0[g];
+        }
+    const bool in_use = row < static_cast<uint32_t>(G);
+    const bool is_small = in_use && (lane & 8u) == 0u, is_tiny = in_use && (lane & 8u) != 0u;
+    const float scale = (lane & 8u) == 0u ? 10.0f : 60.0f;
+    const f3 q2 = mk3(fmaf(ur.x, scale, offr.x), fmaf(ur.y, scale, offr.y), fmaf(ur.z, scale, offr.z));
     uint32_t h2;
     f3 on2;
     const f3 pt2 = scattered_cell(mk3(floorf(q2.x) + cl.si, floorf(q2.y) + cl.sj, floorf(q2.z) + cl.sk), 0.5f, h2);
-    const bool pass2 = project_cell(pt2, off, scale, on2);
+    const bool pass2 = project_cell(pt2, offr, scale, on2);
     const float t2 = static_cast<float>(h2 & 0xffffu) * (1.0f / 65535.0f);
     const uint32_t age2 = h2 >> 16;
     const float d2 = sqrtf(norm_sq(q2 - on2));
-    const float size2 = is_small ? fmaf(0.35f * t2, t2, 0.05f) : fmaf(0.35f, t2, 0.02f);
+    const float size2 = (lane & 8u) == 0u ? fmaf(0.35f * t2, t2, 0.05f) : fmaf(0.35f, t2, 0.02f);
     const float c50 = 50.0f * (d2 - size2);
     const float th = fast_tanh(c50);
     // A small-crater cell takes effect iff it passes the shell and rim tests and its age does not exceed
     // the running minimum, which only cells that took effect lower: the running minimum before cell k is
-    // min(min_age0, ages of the earlier candidates), an exclusive prefix minimum over lanes 0-7.
-    const bool cand = is_small && pass2 && c50 < 0.0f && age2 <= min_age0;
+    // min(min_age0, ages of the earlier candidates), an exclusive prefix minimum over lanes 0-7 of the row.
+    const bool cand = is_small && pass2 && c50 < 0.0f && age2 <= min_age_r;
     const uint32_t xa = cand ? age2 : 0xffffffffu;
     uint32_t incl = xa;
     incl = min(incl, dpp_u<kRowShr1>(0xffffffffu, incl));
@@ -667,12 +709,26 @@ __device__ __forceinline__ float coop_near(const CoopLane& cl, float* lds, f3 of
     incl = min(incl, dpp_u<kRowShr4>(0xffffffffu, incl));
     const uint32_t excl = dpp_u<kRowShr1>(0xffffffffu, incl);
     const bool takes = cand && age2 <= excl;
-    const float crater_small = wave_max(takes ? -0.005f * th : -3.402823466e38f);
-    const uint32_t min_age1 = min(min_age0, wave_min_u(xa));
+    const float crater_small_r = row_max(takes ? -0.005f * th : -3.402823466e38f);
+    const uint32_t min_age1 = min(min_age_r, row_min_u(xa));
     const bool tiny_ok = is_tiny && pass2 && age2 <= min_age1;
-    const float tiny = wave_max(tiny_ok ? -0.004f * size2 * (-0.5f + 0.5f * th) : 0.0f);
-    const float crater = fmaxf(crater_big, crater_small);
-    return s + crater + tiny + fallout + 0.01f * nf1 + 0.4f * nf2;
+    const float tiny_r = row_max(tiny_ok ? -0.004f * size2 * (-0.5f + 0.5f * th) : 0.0f);
+
+    // ---- fallout and the final sum per point -----------------------------------------------
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float fallout_c = 0.0f;
+        if (deposits[g]) {
+            const float n1 = pv[rank[g]], n2 = pv[rank[g] + 1];
+            const float falloff = fast_exp2((2.0f + 3.0f * n1) * fast_log2(lin[g]));
+            fallout_c = 0.1f * falloff * (0.2f + 0.4f * depth[g]) * n2;
+        }
+        const float fallout = wave_sum(fallout_c);
+        const float nf1 = pv[n_fall + 2 * g], nf2 = pv[n_fall + 2 * g + 1];
+        const float crater = fmaxf(crater_big[g], bcast_lane(crater_small_r, 16 * g));
+        out[g] = s[g] + crater + bcast_lane(tiny_r, 16 * g) + fallout + 0.01f * nf1 + 0.4f * nf2;
+    }
+    (void)base;
 }
 
 #pragma clang fp contract(off)
@@ -823,16 +879,40 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
         const bool wants = state == MARCH && result == 0;
         unsigned long long need = __ballot(wants);
         float d2 = 0.0f;
+        while (__popcll(need) >= kCoopGroup) {
+            int src[kCoopGroup];
+            f3 P[kCoopGroup], O[kCoopGroup];
+            float S[kCoopGroup], val[kCoopGroup];
+            uint32_t calls[kCoopGroup];
+#pragma unroll
+            for (int g = 0; g < kCoopGroup; ++g) {
+                src[g] = __ffsll(static_cast<long long>(need)) - 1;
+                need &= need - 1ull;
+                P[g] = mk3(bcast_lane(m.p.x, src[g]), bcast_lane(m.p.y, src[g]), bcast_lane(m.p.z, src[g]));
+                O[g] = mk3(bcast_lane(off.x, src[g]), bcast_lane(off.y, src[g]), bcast_lane(off.z, src[g]));
+                S[g] = bcast_lane(s, src[g]);
+            }
+            coop_near<kCoopGroup>(cl, lds, O, P, S, lane, val, calls);
+#pragma unroll
+            for (int g = 0; g < kCoopGroup; ++g)
+                if (lane == static_cast<uint32_t>(src[g])) {
+                    d2 = val[g];
+                    c_noise += calls[g];
+                    ++c_near;
+                }
+        }
         while (need) {
             const int src = __ffsll(static_cast<long long>(need)) - 1;
             need &= need - 1ull;
-            const f3 P = mk3(bcast_lane(m.p.x, src), bcast_lane(m.p.y, src), bcast_lane(m.p.z, src));
-            const f3 O = mk3(bcast_lane(off.x, src), bcast_lane(off.y, src), bcast_lane(off.z, src));
-            uint32_t calls;
-            const float val = coop_near(cl, lds, O, P, bcast_lane(s, src), lane, calls);
+            const f3 P[1] = {mk3(bcast_lane(m.p.x, src), bcast_lane(m.p.y, src), bcast_lane(m.p.z, src))};
+            const f3 O[1] = {mk3(bcast_lane(off.x, src), bcast_lane(off.y, src), bcast_lane(off.z, src))};
+            const float S[1] = {bcast_lane(s, src)};
+            float val[1];
+            uint32_t calls[1];
+            coop_near<1>(cl, lds, O, P, S, lane, val, calls);
             if (lane == static_cast<uint32_t>(src)) {
-                d2 = val;
-                c_noise += calls;
+                d2 = val[0];
+                c_noise += calls[0];
                 ++c_near;
             }
         }
@@ -986,22 +1066,47 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
         while (need) {
             const int src = __ffsll(static_cast<long long>(need)) - 1;
             need &= need - 1ull;
-            const f3 P = mk3(bcast_lane(lp.x, src), bcast_lane(lp.y, src), bcast_lane(lp.z, src));
-            const f3 O = mk3(bcast_lane(off.x, src), bcast_lane(off.y, src), bcast_lane(off.z, src));
+            const f3 P0 = mk3(bcast_lane(lp.x, src), bcast_lane(lp.y, src), bcast_lane(lp.z, src));
+            const f3 O0 = mk3(bcast_lane(off.x, src), bcast_lane(off.y, src), bcast_lane(off.z, src));
+            f3 P[4], O[4];
+            float S[4], val[4];
+            uint32_t calls[4] = {0, 0, 0, 0};
+            bool any_far = false;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const f3 q = mk3(P.x + (e == 1 ? delta : 0.0f), P.y + (e == 2 ? delta : 0.0f), P.z + (e == 3 ? delta : 0.0f));
-                const float s = norm(q) - 0.5f;
-                float val = s;
-                uint32_t calls = 0;
-                const bool far = static_cast<double>(s) > 0.1;   // wave-uniform: q is
-                if (!far) val = coop_near(cl, lds, O, q, s, lane, calls);
-                if (lane == static_cast<uint32_t>(src)) {
-                    v[e] = val;
-                    c_noise += calls;
-                    if (far) ++c_far;
-                    else ++c_near;
+                P[e] = mk3(P0.x + (e == 1 ? delta : 0.0f), P0.y + (e == 2 ? delta : 0.0f), P0.z + (e == 3 ? delta : 0.0f));
+                O[e] = O0;
+                S[e] = norm(P[e]) - 0.5f;
+                any_far = any_far || (static_cast<double>(S[e]) > 0.1);   // wave-uniform: the points are
+            }
+            uint32_t n_far = 0;
+            if (!any_far) {
+                coop_near<4>(cl, lds, O, P, S, lane, val, calls);   // the usual case: a hit lies in the near field
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    val[e] = S[e];
+                    if (static_cast<double>(S[e]) > 0.1) {
+                        ++n_far;
+                        continue;
+                    }
+                    const f3 P1[1] = {P[e]}, O1[1] = {O0};
+                    const float S1[1] = {S[e]};
+                    float v1[1];
+                    uint32_t c1[1];
+                    coop_near<1>(cl, lds, O1, P1, S1, lane, v1, c1);
+                    val[e] = v1[0];
+                    calls[e] = c1[0];
                 }
+            }
+            if (lane == static_cast<uint32_t>(src)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = val[e];
+                    c_noise += calls[e];
+                }
+                c_far += n_far;
+                c_near += 4u - n_far;
             }
         }
         bool alive = false;
