@@ -479,8 +479,6 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     s->dev.noise_oct = static_cast<const float*>(s->d_oct);
     s->dev.n_sdf = static_cast<uint32_t>(sdf.size());
     s->dev.n_prims = n;
-    if (d->noise_transform) std::memcpy(s->dev.noise, d->noise_transform, sizeof(float) * 12);
-    else std::memset(s->dev.noise, 0, sizeof(s->dev.noise));
     s->n_nodes = static_cast<uint32_t>(bvh.nodes.size());
     s->n_analytic = n_analytic;
     s->n_sdf = static_cast<uint32_t>(sdf.size());

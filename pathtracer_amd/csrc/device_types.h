@@ -58,8 +58,7 @@ struct SceneDev {
     const SdfBox* sdf_boxes;
     uint32_t n_sdf;
     uint32_t n_prims;
-    float noise[12];               // the demo's noiseTransform(): Linear row-major, then the translation
-    // noise() unrolled: octave i samples A_i p + b_i with weight k_i; 13 floats per octave (A row-major,
+    // noise() (PathTracerDemo.cpp:56-70) unrolled: octave i samples A_i p + b_i with weight k_i; 13 floats per octave (A row-major,
     // b, k), 8 octaves (null when the scene has no SDF primitive)
     const float* noise_oct;
 };

@@ -488,17 +488,28 @@ __device__ __forceinline__ float bcast_lane(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+__device__ __forceinline__ uint32_t mul24_lo(int a, int k) {
+    int r;
+    asm("v_mul_i32_i24_e32 %0, %1, %2" : "=v"(r) : "s"(k), "v"(a));
+    return static_cast<uint32_t>(r);
+}
+__device__ __forceinline__ uint32_t shl5(uint32_t h) {
+    uint32_t r;
+    asm("v_lshlrev_b32_e32 %0, 5, %1" : "=v"(r) : "v"(h));
+    return r;
+}
+
 // One cell of for_each_nearby_scattered_point :79-116: hashed, jittered lattice point.  The reference
 // forms the jitter through double; fmaf(scatter/2, m, g) rounds the same exact value once.
 __device__ __forceinline__ f3 scattered_cell(f3 g, float half_scatter, uint32_t& hash) {
-    // lattice coordinates and multipliers fit 24 signed bits, so the full-rate 24-bit multiply returns
-    // the same low 32 bits as the wrapping int multiply of the reference; h * 31 = (h << 5) - h
-    uint32_t h = static_cast<uint32_t>(__mul24(static_cast<int>(g.x), 885889)) + static_cast<uint32_t>(__mul24(static_cast<int>(g.y), 745273)) +
-                 static_cast<uint32_t>(__mul24(static_cast<int>(g.z), 1220689));
+    // Lattice coordinates and multipliers fit 24 signed bits, so the full-rate 24-bit multiply returns
+    // the same low 32 bits as the wrapping int multiply of the reference, and h * 31 = (h << 5) - h.
+    // Both are spelled in asm because the compiler folds the C forms back into quarter-rate v_mul_lo_u32.
+    uint32_t h = mul24_lo(static_cast<int>(g.x), 885889) + mul24_lo(static_cast<int>(g.y), 745273) + mul24_lo(static_cast<int>(g.z), 1220689);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         h |= (h & 0x0f0f0f0fu) << 4;
-        h = (h << 5) - h;
+        h = shl5(h) - h;
     }
     hash = h;
     const float mx = static_cast<float>(h & 0x3ffu) * (1.0f / 512.0f) - 1.0f;
@@ -591,7 +602,7 @@ __device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, const 
     float* pv = lds + 3 * kCoopPts;
     f3 u[G];
     float depth[G], lin[G], crater_big[G];
-    uint32_t rank[G], min_age0[G], base[G], n_dep[G];
+    uint32_t rank[G], min_age0[G];
     bool deposits[G];
     uint32_t n_fall = 0;   // fallout points staged so far
 
@@ -612,21 +623,21 @@ __device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, const 
         const float idist = fast_rsq(fmaxf(dist2, 1e-30f));
         const float dist = dist2 * idist;
         const float c20 = 20.0f * (dist - size);
-        float dp = fast_tanh(c20);
-        if (c20 > 1e-3f) dp = 0.9f * t * dp * fast_rcp(0.02f * fast_rcp(c20) + c20 * c20);
-        depth[g] = dp;
+        const float th = fast_tanh(c20);
+        // tanh(c) for c <= 1e-3, else 0.9 t tanh(c) / (0.02 / c + c^2) = 0.9 t tanh(c) c / (0.02 + c^3)
+        const float rim = 0.9f * t * th * c20 * fast_rcp(fmaf(c20 * c20, c20, 0.02f));
+        depth[g] = c20 > 1e-3f ? rim : th;
         const bool outside = dist >= size;
         lin[g] = fmaxf(0.0f, 1.2f - dist * fast_rcp(size * 5.0f));
         deposits[g] = pass && outside && lin[g] > 0.0f;
-        crater_big[g] = wave_sum(pass ? -0.02f * dp : 0.0f);
+        crater_big[g] = wave_sum(pass ? -0.02f * depth[g] : 0.0f);
         // ages are compared as their 16-bit integers (age = bits / 65535); 0xffff is the initial 1.0
         min_age0[g] = wave_min_u((pass && !outside) ? (hash >> 16) : 0xffffu);
         // stage this point's fallout noise() arguments
         const unsigned long long dmask = __ballot(deposits[g]);
-        n_dep[g] = __popcll(dmask);
-        base[g] = n_fall;
+        const uint32_t n_dep = __popcll(dmask);
         rank[g] = n_fall + 2u * __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(dmask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(dmask), 0u));
-        n_fall += 2u * n_dep[g];
+        n_fall += 2u * n_dep;
         if (deposits[g]) {
             const float k1 = 3.0f * size * idist, k2 = 40.0f * size * idist;
             px[rank[g]] = fmaf(k1, qv.x, on.x);
@@ -636,7 +647,7 @@ __device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, const 
             py[rank[g] + 1] = fmaf(k2, qv.y, on.y);
             pz[rank[g] + 1] = fmaf(k2, qv.z, on.z);
         }
-        noise_calls[g] = 2u * n_dep[g] + 2u;
+        noise_calls[g] = 2u * n_dep + 2u;
     }
     // the two final noise() arguments of every point follow the fallout points
     const uint32_t n_pts = n_fall + 2u * G;
@@ -728,7 +739,6 @@ __device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, const 
         const float crater = fmaxf(crater_big[g], bcast_lane(crater_small_r, 16 * g));
         out[g] = s[g] + crater + bcast_lane(tiny_r, 16 * g) + fallout + 0.01f * nf1 + 0.4f * nf2;
     }
-    (void)base;
 }
 
 #pragma clang fp contract(off)
