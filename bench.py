@@ -26,7 +26,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pathtracer_amd import api, scene as S   # noqa: E402
+from pathtracer_amd import api, scene as S, shard   # noqa: E402
 
 # Algorithmic flop model of CraterBallObject::signedDistance (PathTracerDemo.cpp:361-466), counted on
 # the reference's arithmetic: a far-field evaluation is a norm and a compare; the near-field body
@@ -49,7 +49,7 @@ def parse():
     p.add_argument("--bounces", type=int, default=8)
     p.add_argument("--scene", default="demo", choices=["demo", "random100k", "mixed20k"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the CPU baseline's bounded sample")
+    p.add_argument("--cpu-spp", type=int, default=64, help="samples per pixel of the CPU baseline's bounded sample")
     return p.parse_args()
 
 
@@ -92,14 +92,11 @@ def main():
     ctx.set_profiling(True)
 
     # contiguous block of the global sample range per rank, remainder to the low ranks
-    base, rem = divmod(a.spp, world)
-    my_spp = base + (1 if rank < rem else 0)
-    my_first = rank * base + min(rank, rem)
+    my_first, my_spp = shard.sample_range(a.spp, world, rank)
 
     d_sum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     d_ldr = torch.empty_like(d_sum)
     h_out = torch.empty((H, W, 3), dtype=torch.float32).pin_memory() if rank == 0 else None
-    n_floats = H * W * 3
 
     agg = {}
 
@@ -108,9 +105,7 @@ def main():
         st = None
         if my_spp:
             st = ctx.render_accumulate(dscene, cam, W, H, a.bounces, my_spp, d_sum.data_ptr(), seed=2024, first_sample=my_first)
-        if dist is not None:
-            dist.all_reduce(d_sum)
-        ctx.scale_device(d_sum.data_ptr(), 1.0 / a.spp, n_floats, d_sum.data_ptr())
+        shard.reduce_frame(d_sum, a.spp, dist)   # RCCL all-reduce + 1/spp
         ctx.tonemap_device(1, d_sum.data_ptr(), d_ldr.data_ptr(), W, H)
         if rank == 0:
             h_out.copy_(d_ldr, non_blocking=True)
