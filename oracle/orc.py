@@ -254,13 +254,27 @@ class OracleScene:
 
 
 class Reference(_Api):
-    """oracle/_ref/libref.so -- the reference's own code."""
+    """oracle/_ref/libref.so -- the reference's own code -- or, given a path, another build of the same
+    harness (oracle/ref_harness.cpp compiled against this repository's host API headers)."""
 
-    def __init__(self):
-        dll = ref()
-        if dll is None:
-            raise RuntimeError("oracle/_ref/libref.so has not been built (needs the reference checkout)")
+    def __init__(self, path=None):
+        if path is None:
+            dll = ref()
+            if dll is None:
+                raise RuntimeError("oracle/_ref/libref.so has not been built (needs the reference checkout)")
+        else:
+            dll = C.CDLL(path)
+            dll.ref_scene_create.restype = C.c_void_p
         super().__init__(dll, "ref_")
+
+    def has(self, name):
+        return hasattr(self.dll, name)
+
+    def set_noise(self, noise12):
+        """Harness builds without the demo's source block take the noise transform as data."""
+        if self.has("ref_set_noise"):
+            n = _f(noise12)
+            self.dll.ref_set_noise(_fp(n))
 
     def init_noise(self, seed):
         out = np.zeros(12, np.float32)

@@ -44,7 +44,17 @@ std::default_random_engine& randomEngine() noexcept {
     return re;
 }
 
+#ifdef DEMO_SDF_INC
 #include DEMO_SDF_INC
+#else
+// Built against this repository's own headers without the demo's source block: the crater ball is the
+// library's CraterBall type and its noise transform is set by ref_set_noise().
+static Affine g_noise;
+class CraterBallObject : public CraterBall {
+public:
+    CraterBallObject(BasicMaterial m, Vec offset) : CraterBall(m, offset, g_noise) {}
+};
+#endif
 
 namespace {
 
@@ -95,12 +105,19 @@ struct RefScene {
 
 extern "C" {
 
+#ifdef DEMO_SDF_INC
 // Initialises the demo's process-wide noise transform (PathTracerDemo.cpp:37-54) from an engine
 // seeded `seed` on the calling thread and returns it.  Only the first call in a process draws.
 void ref_init_noise(uint64_t seed, float out12[12]) {
     randomEngine().seed(static_cast<std::default_random_engine::result_type>(seed));
     store_aff(noiseTransform(), out12);
 }
+void ref_noise(uint32_t n, const float* pos, float* out_v) {
+    for (uint32_t i = 0; i < n; ++i) out_v[i] = noise(Pos(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]));
+}
+#else
+void ref_set_noise(const float in12[12]) { g_noise = load_aff(in12); }
+#endif
 
 void ref_rotation_x(float a, float out[9]) { auto l = Linear::RotationX(a); for (int i = 0; i < 9; ++i) out[i] = l[i]; }
 void ref_rotation_y(float a, float out[9]) { auto l = Linear::RotationY(a); for (int i = 0; i < 9; ++i) out[i] = l[i]; }
@@ -177,10 +194,6 @@ void ref_normal_local(uint32_t kind, const float params[9], uint32_t n, const fl
 void ref_sdf_craterball(const float off[3], uint32_t n, const float* pos, float* out_d) {
     const auto o = CraterBallObject(BasicMaterial{}, Vec(off[0], off[1], off[2]));
     for (uint32_t i = 0; i < n; ++i) out_d[i] = o.signedDistance(Pos(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]));
-}
-
-void ref_noise(uint32_t n, const float* pos, float* out_v) {
-    for (uint32_t i = 0; i < n; ++i) out_v[i] = noise(Pos(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]));
 }
 
 void ref_camera_rays(const float cam16[16], uint32_t n, const float* sx, const float* sy, uint64_t seed,

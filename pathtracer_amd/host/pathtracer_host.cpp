@@ -1,0 +1,847 @@
+// Host side of include/pathtracer/pathtracer.hpp.
+//
+// Two halves: (1) the per-ray host functions of the public API, written to the reference's arithmetic
+// (operation order, epsilons, quirks) so that values computed on the host agree with the device and
+// with the reference; (2) the glue that flattens a Scene and drives the GPU through the C ABI
+// (include/mipt.h).  Built with -ffp-contract=off.  Citations are file:line of the reference checkout.
+#include "pathtracer/pathtracer.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <stdexcept>
+
+#include "mipt.h"
+
+// ================================================================================================
+// random numbers
+// ================================================================================================
+// Weak, so that a program may link its own definition (a fixed seed for reproducible host sampling).
+__attribute__((weak)) std::default_random_engine& randomEngine() noexcept {   // src/RandomNumberGenerator.cpp:3-6
+    static thread_local std::default_random_engine engine{std::random_device{}()};
+    return engine;
+}
+
+// ================================================================================================
+// linear algebra: delegated to the C ABI's host helpers, which keep the reference's operation order
+// ================================================================================================
+namespace {
+Linear linear_from(const float* m) { return Linear(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8]); }
+void affine_to(const Affine& a, float* o) {
+    std::memcpy(o, a.linear.data(), 9 * sizeof(float));
+    o[9] = a.translation.x;
+    o[10] = a.translation.y;
+    o[11] = a.translation.z;
+}
+Affine affine_from(const float* m) { return Affine(linear_from(m), Vec(m[9], m[10], m[11])); }
+Linear rotation(char axis, float angle) {
+    float m[9];
+    mipt_rotation(axis, 1, &angle, m);
+    return linear_from(m);
+}
+}   // namespace
+
+Linear Linear::RotationX(float a) noexcept { return rotation('x', a); }
+Linear Linear::RotationY(float a) noexcept { return rotation('y', a); }
+Linear Linear::RotationZ(float a) noexcept { return rotation('z', a); }
+
+Linear Linear::Rotation(Vec u, float a) noexcept {   // axis-angle, src/LinearAlgebra.cpp:120-130
+    const float c = std::cos(a), s = std::sin(a), omc = 1.0f - c;
+    return Linear(c + u.x * u.x * omc, u.x * u.y * omc - u.z * s, u.x * u.z * omc + u.y * s,
+                  u.y * u.x * omc + u.z * s, c + u.y * u.y * omc, u.y * u.z * omc - u.x * s,
+                  u.z * u.x * omc - u.y * s, u.z * u.y * omc + u.x * s, c + u.z * u.z * omc);
+}
+
+float Linear::determinant() const noexcept {   // :201-205
+    const auto& m = m_data;
+    return (m[0] * m[4] * m[8]) + (m[1] * m[5] * m[6]) + (m[2] * m[3] * m[7]) - (m[2] * m[4] * m[6]) - (m[1] * m[3] * m[8]) - (m[0] * m[5] * m[7]);
+}
+
+std::optional<Linear> Linear::inverse() const noexcept {
+    float f[12] = {}, inv[12];
+    std::memcpy(f, m_data.data(), sizeof(float) * 9);
+    if (mipt_affine_inverse(1, f, inv) != MIPT_OK) return std::nullopt;
+    return linear_from(inv);
+}
+
+Linear& Linear::operator*=(const Linear& other) noexcept {
+    *this = (*this) * other;
+    return *this;
+}
+
+std::optional<Affine> Affine::inverse() const noexcept {   // :258-264
+    float f[12], inv[12];
+    affine_to(*this, f);
+    if (mipt_affine_inverse(1, f, inv) != MIPT_OK) return std::nullopt;
+    return affine_from(inv);
+}
+
+Linear operator-(const Linear& A) noexcept {
+    Linear r;
+    for (std::size_t i = 0; i < 9; ++i) r[i] = -A[i];
+    return r;
+}
+Linear operator+(const Linear& A, const Linear& B) noexcept {
+    Linear r;
+    for (std::size_t i = 0; i < 9; ++i) r[i] = A[i] + B[i];
+    return r;
+}
+Linear operator-(const Linear& A, const Linear& B) noexcept {
+    Linear r;
+    for (std::size_t i = 0; i < 9; ++i) r[i] = A[i] - B[i];
+    return r;
+}
+Linear operator*(const Linear& A, float t) noexcept {
+    Linear r;
+    for (std::size_t i = 0; i < 9; ++i) r[i] = t * A[i];
+    return r;
+}
+Linear operator*(float t, const Linear& A) noexcept { return A * t; }
+Linear operator/(const Linear& A, float t) noexcept { return A * (1.0f / t); }
+Linear operator*(const Linear& A, const Linear& B) noexcept {   // rows times columns, :389-395
+    Linear r;
+    for (std::size_t i = 0; i < 3; ++i)
+        for (std::size_t j = 0; j < 3; ++j) r(i, j) = A.row(i) * B.column(j);
+    return r;
+}
+Affine operator*(const Affine& A, const Linear& L) noexcept { return Affine(A.linear * L, A.translation); }
+Affine operator*(const Linear& L, const Affine& A) noexcept { return Affine(L) * A; }
+Affine operator*(const Affine& A, const Affine& B) noexcept { return Affine(A.linear * B.linear, A.linear * B.translation + A.translation); }
+
+// ================================================================================================
+// geometry (src/Geometry.cpp)
+// ================================================================================================
+namespace {
+constexpr float kPi = 3.141592653589793f;
+constexpr float kEps = 1e-3f;   // :8
+}
+
+float Sphere::surfaceArea() const noexcept { return 4.0f * kPi * radius * radius; }
+float Sphere::volume() const noexcept { return (4.0f / 3.0f) * kPi * radius * radius * radius; }
+float Rectangle::surfaceArea() const noexcept { return 8.0f * (halfSize.x * halfSize.y + halfSize.x * halfSize.z + halfSize.y * halfSize.z); }
+
+float Rectangle::signedDistance(Pos p) const noexcept {   // :66-75
+    const float dx = std::abs(p.x) - halfSize.x, dy = std::abs(p.y) - halfSize.y, dz = std::abs(p.z) - halfSize.z;
+    return Vec(std::max(dx, 0.0f), std::max(dy, 0.0f), std::max(dz, 0.0f)).norm() + std::min(std::max(std::max(dx, dy), dz), 0.0f);
+}
+
+// Largest |p_k / half_k| wins; ties prefer z, then y; the sign of 0 counts as negative (:77-103).
+Vec Rectangle::normal(Pos p) const noexcept {
+    const float ax = std::abs(p.x / halfSize.x), ay = std::abs(p.y / halfSize.y), az = std::abs(p.z / halfSize.z);
+    const auto sgn = [](float v) { return v > 0.0f ? 1.0f : -1.0f; };
+    if (ax > ay && ax > az) return Vec(sgn(p.x), 0.0f, 0.0f);
+    if (!(ax > ay) && ay > az) return Vec(0.0f, sgn(p.y), 0.0f);
+    return Vec(0.0f, 0.0f, sgn(p.z));
+}
+
+AxisAlignedBox::AxisAlignedBox(Pos corner, Pos opposite) noexcept   // :348-358
+    : center(corner + 0.5f * (opposite - corner)),
+      halfSize(Vec(0.5f * std::abs(corner.x - opposite.x), 0.5f * std::abs(corner.y - opposite.y), 0.5f * std::abs(corner.z - opposite.z))) {}
+
+AxisAlignedBox boxContaining(const AxisAlignedBox& a, const AxisAlignedBox& b) noexcept {   // :105-140
+    const Pos a0 = a.center - a.halfSize, a1 = a.center + a.halfSize, b0 = b.center - b.halfSize, b1 = b.center + b.halfSize;
+    return AxisAlignedBox(Pos(std::min(a0.x, b0.x), std::min(a0.y, b0.y), std::min(a0.z, b0.z)),
+                          Pos(std::max(a1.x, b1.x), std::max(a1.y, b1.y), std::max(a1.z, b1.z)));
+}
+
+Vec bounce(const Vec& inbound, const Vec& normal) noexcept { return inbound - (2.0f * ((inbound * normal) * normal)); }   // :142-144
+
+std::optional<Pos> intersect(const Ray& ray, const Triangle& tri) noexcept {   // Moeller-Trumbore, :146-171
+    const Vec e1 = tri.b - tri.a, e2 = tri.c - tri.a;
+    const Vec h = ray.dir ^ e2;
+    const float det = e1 * h;
+    if (std::abs(det) < kEps) return std::nullopt;
+    const float f = 1.0f / det;
+    const Vec s = ray.pos - tri.a;
+    const float u = f * (s * h);
+    if (u < 0.0f || u > 1.0f) return std::nullopt;
+    const Vec q = s ^ e1;
+    const float v = f * (ray.dir * q);
+    if (v < 0.0f || u + v > 1.0f) return std::nullopt;
+    const float t = f * (e2 * q);
+    if (t > kEps) return ray.pos + t * ray.dir;
+    return std::nullopt;
+}
+
+std::optional<Pos> intersect(const Ray& ray, const Sphere& sphere) noexcept {   // :173-201
+    const float a = ray.dir.normSquared();
+    const float b = 2.0f * (ray.dir * ray.pos.toVec());
+    const float c = ray.pos.toVec().normSquared() - (sphere.radius * sphere.radius);
+    const float disc = b * b - 4.0f * a * c;
+    if (disc <= 0.0f) return std::nullopt;
+    const float root = std::sqrt(disc);
+    const float t0 = (-b - root) / (2.0f * a), t1 = (-b + root) / (2.0f * a);
+    float t;
+    if (t0 > kEps) t = t1 > kEps ? std::min(t0, t1) : t0;
+    else if (t1 > kEps) t = t1;
+    else return std::nullopt;
+    return ray.pos + t * ray.dir;
+}
+
+// Six face planes; a face is skipped when the direction component is below 1e-3 in magnitude, t > 0
+// carries no epsilon, and from inside the exit face is returned (:203-252).
+std::optional<Pos> intersect(const Ray& ray, const Rectangle& box) noexcept {
+    const Vec lo = -ray.pos.toVec() - box.halfSize, hi = -ray.pos.toVec() + box.halfSize;
+    const float d[3] = {ray.dir.x, ray.dir.y, ray.dir.z}, l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+    std::optional<float> best;
+    for (int k = 0; k < 3; ++k) {
+        if (std::abs(d[k]) < kEps) continue;
+        for (const float plane : {l[k], h[k]}) {
+            const float t = plane / d[k];
+            if (!(t > 0.0f)) continue;
+            bool within = true;
+            for (int j = 0; j < 3; ++j) {
+                if (j == k) continue;
+                const float v = d[j] * t;
+                within = within && v >= l[j] && v <= h[j];
+            }
+            if (within) best = best ? std::min(*best, t) : t;
+        }
+    }
+    if (!best) return std::nullopt;
+    return ray.pos + ((*best) * ray.dir);
+}
+
+std::optional<Pos> intersect(const Ray& ray, const AxisAlignedBox& b) noexcept {   // :254-261
+    const auto p = intersect(Ray(ray.dir, ray.pos - b.center.toVec()), Rectangle(b.halfSize));
+    if (!p) return std::nullopt;
+    return (*p) + b.center.toVec();
+}
+
+bool inside(const Pos& p, const Sphere& s) noexcept { return p.toVec().normSquared() <= (s.radius * s.radius); }
+bool inside(const Pos& p, const Rectangle& b) noexcept {
+    return std::abs(p.x) <= b.halfSize.x && std::abs(p.y) <= b.halfSize.y && std::abs(p.z) <= b.halfSize.z;
+}
+bool inside(const Pos& p, const AxisAlignedBox& b) noexcept { return inside(p - b.center.toVec(), Rectangle(b.halfSize)); }
+
+std::pair<float, float> randomPointInCircle() noexcept {   // :278-288
+    std::uniform_real_distribution<float> dist{-1.0f, 1.0f};
+    for (;;) {
+        const float x = dist(randomEngine()), y = dist(randomEngine());
+        if (x * x + y * y <= 1.0f) return {x, y};
+    }
+}
+
+std::pair<Vec, Vec> orthogonalPair(Vec v) noexcept {   // :290-299
+    v = v.unit();
+    const bool alongX = (v ^ Vec(1.0f, 0.0f, 0.0f)).normSquared() < 0.1;
+    const Vec w = alongX ? Vec(0.0f, 1.0f, 0.0f) : Vec(1.0f, 0.0f, 0.0f);
+    const Vec v1 = w ^ v, v2 = v1 ^ v;
+    return {v1.unit(), v2.unit()};
+}
+
+Vec randomPointOnHemisphereUniform(Vec normal) noexcept {   // :301-318
+    normal = normal.unit();
+    std::uniform_real_distribution<float> dist{-1.0f, 1.0f};
+    for (;;) {
+        const float x = dist(randomEngine()), y = dist(randomEngine()), z = dist(randomEngine());
+        const float l2 = (x * x) + (y * y) + (z * z);
+        if (l2 > 1.0f || l2 < kEps) continue;
+        const Vec v(x, y, z);
+        if ((v * normal) <= 0.0f) continue;
+        return v.unit();
+    }
+}
+
+Vec randomPointOnHemisphereCosine(Vec normal) noexcept {   // :320-341
+    normal = normal.unit();
+    std::uniform_real_distribution<float> dist{-1.0f, 1.0f};
+    for (;;) {
+        const float x = dist(randomEngine()), y = dist(randomEngine());
+        const float l2 = (x * x) + (y * y);
+        if (l2 > 1.0f) continue;
+        const float z = std::sqrt(1.0f - l2);
+        const auto [v1, v2] = orthogonalPair(normal);
+        return (z * normal) + (x * v1) + (y * v2);
+    }
+}
+
+// ================================================================================================
+// material (src/BasicMaterial.cpp)
+// ================================================================================================
+BasicMaterial::BasicMaterial() noexcept : m_p{0.3f, 0.3f, 0.9f, 1.0f, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.5f, 0.9f, 0.9f, 0.9f} {}   // :9-18
+
+void BasicMaterial::setDiffuseReflection(float r) noexcept { m_p[0] = r; }
+void BasicMaterial::setSpecularReflection(float r) noexcept { m_p[1] = r; }
+void BasicMaterial::setSpecularSharpness(float r) noexcept { m_p[2] = r; }
+void BasicMaterial::setReflectedAbsorption(Color c) noexcept { m_p[3] = c.r; m_p[4] = c.g; m_p[5] = c.b; }
+void BasicMaterial::setEmittedLuminance(Color c) noexcept { m_p[6] = c.r; m_p[7] = c.g; m_p[8] = c.b; }
+void BasicMaterial::setTransmittance(float r) noexcept { m_p[9] = r; }
+void BasicMaterial::setIndexOfRefraction(float i) noexcept { m_p[10] = i; }
+void BasicMaterial::setInternalAbsorption(Color c) noexcept { m_p[11] = c.r; m_p[12] = c.g; m_p[13] = c.b; }
+
+// Inside hits are deterministic; outside hits pick diffuse / specular / transmission with probabilities
+// proportional to the three weights; every lobe returns the emitted luminance and the reflected
+// absorption without pdf or cosine factors (:97-159).
+ColorBounce BasicMaterial::deflect(const Vec& inbound, const Vec& normal) const noexcept {
+    const float ior = m_p[10];
+    if (inbound * normal >= 0.0f) {
+        const Vec v = (inbound + ((inbound * normal) * (1.0f - ior) * normal)).unit();
+        if (v * normal >= 0.0f) return ColorBounce(Color(0.0f, 0.0f, 0.0f), Color(1.0f, 1.0f, 1.0f), v, normal);
+        return ColorBounce(Color(0.0f, 1.0f, 1.0f), Color(0.0f, 0.0f, 0.0f), bounce(inbound, -normal), normal);
+    }
+    const float reflection = m_p[0] + m_p[1];
+    const float options = reflection + m_p[9];
+    std::uniform_real_distribution<float> dist{0.0f, options};
+    const float which = dist(randomEngine());
+    Vec out;
+    if (which < reflection) {
+        if (which < m_p[0]) out = randomPointOnHemisphereCosine(normal);
+        else out = (bounce(inbound, normal) + (1.0f - m_p[2]) * randomPointOnHemisphereCosine(normal)).unit();
+    } else {
+        out = (inbound + ((inbound * normal) * (1.0f - 1.0f / ior) * normal)).unit();
+    }
+    return ColorBounce(emittedLuminance(), reflectedAbsorption(), out, normal);
+}
+
+// ================================================================================================
+// objects (src/Object.cpp)
+// ================================================================================================
+void Object::setTransformation(const Affine& t) noexcept {
+    m_transformation = t;
+    const auto inv = t.inverse();
+    if (!inv) {   // the reference asserts; a determinant below 1e-6 also covers mirrors and small scales
+        std::fprintf(stderr, "pathtracer: Object::setTransformation: transformation is not invertible (determinant < 1e-6)\n");
+        std::abort();
+    }
+    m_inverseTransformation = *inv;
+}
+
+std::optional<Pos> Object::hitRay(const Ray& ray) const noexcept {   // :22-33
+    const Ray local(m_inverseTransformation * ray.dir, m_inverseTransformation * ray.pos);
+    const auto hit = hitLocalRay(local);
+    if (!hit) return std::nullopt;
+    return m_transformation * (*hit);
+}
+
+ColorBounce Object::deflectRay(const Ray& ray) const noexcept {   // :35-44
+    const Ray local(m_inverseTransformation * ray.dir, m_inverseTransformation * ray.pos);
+    ColorBounce b = deflectLocalRay(local);
+    b.rayDirection = m_transformation * b.rayDirection;
+    return b;
+}
+
+AxisAlignedBox Object::getBoundingBox() const noexcept {   // :46-80
+    const AxisAlignedBox bb = getLocalBoundingBox();
+    const float big = std::numeric_limits<float>::max(), low = std::numeric_limits<float>::lowest();
+    Pos lo(big, big, big), hi(low, low, low);
+    for (int s = 0; s < 8; ++s) {
+        const Vec corner((s & 4) ? -bb.halfSize.x : bb.halfSize.x, (s & 2) ? -bb.halfSize.y : bb.halfSize.y, (s & 1) ? -bb.halfSize.z : bb.halfSize.z);
+        const Pos u = m_transformation * (bb.center + corner);
+        lo = Pos(std::min(lo.x, u.x), std::min(lo.y, u.y), std::min(lo.z, u.z));
+        hi = Pos(std::max(hi.x, u.x), std::max(hi.y, u.y), std::max(hi.z, u.z));
+    }
+    return AxisAlignedBox(lo, hi);
+}
+
+TriangleObject::TriangleObject(Triangle g, BasicMaterial m) : geometry(g), material(m) {}
+std::optional<Pos> TriangleObject::hitLocalRay(const Ray& ray) const noexcept { return intersect(ray, geometry); }
+ColorBounce TriangleObject::deflectLocalRay(const Ray& ray) const noexcept { return material.deflect(ray.dir, geometry.normal()); }
+AxisAlignedBox TriangleObject::getLocalBoundingBox() const noexcept {   // padded by 1e-3, :96-108
+    const auto& g = geometry;
+    return AxisAlignedBox(Pos(std::min({g.a.x, g.b.x, g.c.x}) - 1e-3f, std::min({g.a.y, g.b.y, g.c.y}) - 1e-3f, std::min({g.a.z, g.b.z, g.c.z}) - 1e-3f),
+                          Pos(std::max({g.a.x, g.b.x, g.c.x}) + 1e-3f, std::max({g.a.y, g.b.y, g.c.y}) + 1e-3f, std::max({g.a.z, g.b.z, g.c.z}) + 1e-3f));
+}
+void TriangleObject::describeForDevice(mipt_host::DevicePrimitive& o) const noexcept {
+    o.kind = MIPT_TRIANGLE;
+    const float p[9] = {geometry.a.x, geometry.a.y, geometry.a.z, geometry.b.x, geometry.b.y, geometry.b.z, geometry.c.x, geometry.c.y, geometry.c.z};
+    std::memcpy(o.params, p, sizeof(p));
+    o.material = &material;
+    o.type_name = "TriangleObject";
+}
+
+SphereObject::SphereObject(Sphere g, BasicMaterial m) noexcept : geometry(g), material(m) {}
+std::optional<Pos> SphereObject::hitLocalRay(const Ray& ray) const noexcept { return intersect(ray, geometry); }
+ColorBounce SphereObject::deflectLocalRay(const Ray& ray) const noexcept { return material.deflect(ray.dir, geometry.normal(ray.pos)); }
+AxisAlignedBox SphereObject::getLocalBoundingBox() const noexcept {
+    const float h = geometry.radius + 1e-3f;
+    return AxisAlignedBox(Pos(0.0f, 0.0f, 0.0f), Vec(h, h, h));
+}
+void SphereObject::describeForDevice(mipt_host::DevicePrimitive& o) const noexcept {
+    o.kind = MIPT_SPHERE;
+    o.params[0] = geometry.radius;
+    o.material = &material;
+    o.type_name = "SphereObject";
+}
+
+BoxObject::BoxObject(Rectangle g, BasicMaterial m) noexcept : geometry(g), material(m) {}
+std::optional<Pos> BoxObject::hitLocalRay(const Ray& ray) const noexcept { return intersect(ray, geometry); }
+ColorBounce BoxObject::deflectLocalRay(const Ray& ray) const noexcept { return material.deflect(ray.dir, geometry.normal(ray.pos)); }
+AxisAlignedBox BoxObject::getLocalBoundingBox() const noexcept {
+    return AxisAlignedBox(Pos(0.0f, 0.0f, 0.0f), Vec(geometry.halfSize.x + 1e-3f, geometry.halfSize.y + 1e-3f, geometry.halfSize.z + 1e-3f));
+}
+void BoxObject::describeForDevice(mipt_host::DevicePrimitive& o) const noexcept {
+    o.kind = MIPT_BOX;
+    o.params[0] = geometry.halfSize.x;
+    o.params[1] = geometry.halfSize.y;
+    o.params[2] = geometry.halfSize.z;
+    o.material = &material;
+    o.type_name = "BoxObject";
+}
+
+// FractalObject (src/Object.cpp:160-252).  Its hitLocalRay intersects the WORLD bounding box with the
+// local ray, as the reference does.
+std::optional<Pos> FractalObject::hitLocalRay(const Ray& ray) const noexcept {
+    const auto start = intersect(ray, getBoundingBox());
+    if (!start) return std::nullopt;
+    Pos p = *start;
+    for (std::size_t i = 0; i < 256; ++i) {
+        const float d = signedDistance(p);
+        if (d < 1e-3f) return p;
+        p = p + d * ray.dir;
+    }
+    return std::nullopt;
+}
+ColorBounce FractalObject::deflectLocalRay(const Ray& ray) const noexcept {
+    const float delta = 1e-3f;
+    const Vec dx(delta, 0.0f, 0.0f), dy(0.0f, delta, 0.0f), dz(0.0f, 0.0f, delta);
+    const Vec n = (Vec(signedDistance(ray.pos + dx) - signedDistance(ray.pos - dx), signedDistance(ray.pos + dy) - signedDistance(ray.pos - dy),
+                       signedDistance(ray.pos + dz) - signedDistance(ray.pos - dz)) /
+                   delta)
+                      .unit();
+    return material.deflect(ray.dir, n);
+}
+AxisAlignedBox FractalObject::getLocalBoundingBox() const noexcept { return AxisAlignedBox(Pos(0.0f, 0.0f, 0.0f), Vec(2.0f, 2.0f, 2.0f)); }
+float FractalObject::signedDistance(const Pos& p) const noexcept {
+    const auto fold = [](float v) {
+        if (v < -0.5f) return v + 0.5f;
+        if (v > 0.5f) return v - 0.5f;
+        v *= 2.0f;
+        return (v - std::round(v)) / 2.0f;
+    };
+    return Vec(fold(p.x), fold(p.y), fold(p.z)).norm() - 0.2f;
+}
+
+// ================================================================================================
+// the demo's CraterBallObject, recognised without its cooperation
+// ================================================================================================
+bool mipt_host::describeKnownDemoSdf(const char* name, std::size_t derived_size, std::size_t base_size, const void* object, DevicePrimitive& out) noexcept {
+    // Itanium mangling of a global class: <length><name>.  The class has exactly one data member, a Vec,
+    // laid out directly behind the SDFObjectCRTP base (PathTracerDemo.cpp:481-482).
+    if (std::strcmp(name, "16CraterBallObject") != 0) return false;
+    if (derived_size < base_size + sizeof(Vec) || derived_size > base_size + sizeof(Vec) + 8) return false;
+    float off[3];
+    std::memcpy(off, static_cast<const char*>(object) + base_size, sizeof(off));
+    out.kind = MIPT_CRATERBALL;
+    out.params[0] = off[0];
+    out.params[1] = off[1];
+    out.params[2] = off[2];
+    return true;
+}
+
+// ---- CraterBall: host evaluation of the SDF (PathTracerDemo.cpp:26-116, 361-466) ----------------
+namespace {
+float triangle_wave(float x) { return -1.0f + 4.0f * std::abs(x - 0.25f - std::floor(x + 0.25f)); }
+
+float fbm(const Affine& T, Pos p) {   // noise(): 8 octaves, weight 0.02 * 0.9^i, lacunarity 1.1
+    float v = 0.0f, k = 0.02f;
+    for (int i = 0; i < 8; ++i) {
+        p = T * p;
+        v += k * (triangle_wave(p.x) + triangle_wave(p.y) + triangle_wave(p.z));
+        p = Pos(p.x * 1.1f, p.y * 1.1f, p.z * 1.1f);
+        k *= 0.9f;
+    }
+    return v;
+}
+
+// Hashed, jittered lattice points around `location`; the jitter expression is evaluated in double
+// and narrowed, as the `-1.0` literal in the reference makes it.
+template <class F>
+void lattice_points(Pos location, float scatter, int radius, F&& f) {
+    const Pos origin(std::floor(location.x), std::floor(location.y), std::floor(location.z));
+    for (int i = -radius + 1; i <= radius; ++i)
+        for (int j = -radius + 1; j <= radius; ++j)
+            for (int k = -radius + 1; k <= radius; ++k) {
+                const Pos g = origin + Vec(static_cast<float>(i), static_cast<float>(j), static_cast<float>(k));
+                std::uint32_t h = static_cast<std::uint32_t>(static_cast<int>(g.x)) * 885889u + static_cast<std::uint32_t>(static_cast<int>(g.y)) * 745273u +
+                                  static_cast<std::uint32_t>(static_cast<int>(g.z)) * 1220689u;
+                for (int r = 0; r < 4; ++r) {
+                    h |= (h & 0x0f0f0f0fu) << 4;
+                    h *= 31u;
+                }
+                const auto jit = [&](float c, std::uint32_t bits) { return static_cast<float>(c + scatter * 0.5f * (-1.0 + static_cast<float>(bits & 0x3ffu) / 512.0f)); };
+                f(Pos(jit(g.x, h), jit(g.y, h >> 10), jit(g.z, h >> 20)), h);
+            }
+}
+}   // namespace
+
+CraterBall::CraterBall(BasicMaterial mat, Vec offset, Affine noise) : SDFObjectCRTP(mat), m_offset(offset), m_noise(noise) {}
+
+float CraterBall::signedDistance(const Pos& pos) const noexcept {
+    const float sphere = pos.toVec().norm() - 0.5f;
+    if (sphere > 0.1) return sphere;
+    const Vec inward = -pos.toVec().unit();
+    float crater = 0.0f, tiny = 0.0f, fallout = 0.0f, min_age = 1.0f;
+    const auto unit16 = [](std::uint32_t v) { return static_cast<float>(v & 0xffffu) / static_cast<float>(0xffff); };
+    const auto project = [&](Pos point, float scale) { return m_offset + ((point - m_offset).toVec().unit() * scale).toPos(); };
+    {   // big craters
+        const Pos query = m_offset + (inward * 2.0f).toPos();
+        lattice_points(query, 0.6f, 2, [&](Pos point, std::uint32_t hash) {
+            const float t = unit16(hash), age = unit16(hash >> 16), size = 0.05f + 0.4f * t * t;
+            const Pos on = project(point, 2.0f);
+            const float dist = (query - on).norm();
+            if (!((on - point).normSquared() < 0.1f)) return;
+            const float c = 20.0f * (dist - size);
+            float depth = std::tanh(c);
+            if (c > 1e-3f) depth = 0.9f * t * depth / (0.02f / c + c * c);
+            crater -= 0.02f * depth;
+            if (dist >= size) {
+                const float lin = std::max(0.0f, 1.2f - dist / (size * 5.0f));
+                const Vec away = (query - on).unit();
+                const float falloff = std::pow(lin, 2.0f + 3.0f * fbm(m_noise, on + 3.0f * size * away));
+                fallout += 0.1f * falloff * (0.2f + 0.4f * depth) * fbm(m_noise, on + 40.0f * size * away);
+            } else {
+                min_age = std::min(age, min_age);
+            }
+        });
+    }
+    {   // small craters
+        const Pos query = m_offset + (inward * 10.0f).toPos();
+        lattice_points(query, 1.0f, 1, [&](Pos point, std::uint32_t hash) {
+            const float t = unit16(hash), age = unit16(hash >> 16);
+            if (age > min_age) return;
+            const float size = 0.05f + 0.35f * t * t;
+            const Pos on = project(point, 10.0f);
+            if (!((on - point).normSquared() < 0.1f)) return;
+            const float c = 50.0f * ((query - on).norm() - size);
+            if (c < 0.0f) {
+                min_age = std::min(age, min_age);
+                crater = std::max(-0.005f * std::tanh(c), crater);
+            }
+        });
+    }
+    {   // tiny craters
+        const Pos query = m_offset + (inward * 60.0f).toPos();
+        lattice_points(query, 1.0f, 1, [&](Pos point, std::uint32_t hash) {
+            const float t = unit16(hash), age = unit16(hash >> 16), size = 0.02f + 0.35f * t;
+            const Pos on = project(point, 60.0f);
+            if (!((on - point).normSquared() < 0.1f) || age > min_age) return;
+            tiny = std::max(-0.004f * size * (-0.5f + 0.5f * std::tanh(50.0f * ((query - on).norm() - size))), tiny);
+        });
+    }
+    return sphere + crater + tiny + fallout + 0.01f * fbm(m_noise, ((pos + m_offset).toVec() * 20.0f).toPos()) +
+           0.4f * fbm(m_noise, ((pos + m_offset).toVec() * 1.5f).toPos());
+}
+
+bool mipt_host::DeviceSdf<CraterBall>::describe(const CraterBall& ball, DevicePrimitive& out) noexcept {
+    out.kind = MIPT_CRATERBALL;
+    out.params[0] = ball.offset().x;
+    out.params[1] = ball.offset().y;
+    out.params[2] = ball.offset().z;
+    static_assert(sizeof(Affine) == 12 * sizeof(float), "Affine is 12 packed floats");
+    out.noise = reinterpret_cast<const float*>(&ball.noise());
+    return true;
+}
+
+// The demo defines `const Affine& noiseTransform() noexcept` in its own translation unit; when this
+// library is linked into such a program the weak reference resolves to it.
+const Affine& noiseTransform() noexcept __attribute__((weak));
+
+// ================================================================================================
+// object tree (src/ObjectTree.cpp): closest hit over all leaves; built by median splits
+// ================================================================================================
+namespace ObjectTree {
+
+InternalNode::InternalNode(std::unique_ptr<Node> a, std::unique_ptr<Node> b) noexcept
+    : Node(boxContaining(a->boundingBox, b->boundingBox)), m_childA(std::move(a)), m_childB(std::move(b)) {}
+
+std::optional<std::pair<Pos, const Object*>> InternalNode::hit(const Ray& ray) const noexcept {   // :22-63
+    const auto a = m_childA->hit(ray), b = m_childB->hit(ray);
+    if (a && b) {
+        const float ta = (a->first - ray.pos) * ray.dir, tb = (b->first - ray.pos) * ray.dir;
+        return tb < ta ? b : a;
+    }
+    return a ? a : b;
+}
+
+LeafNode::LeafNode(const Object* object) noexcept : Node(object->getBoundingBox()), m_object(object) {}
+
+std::optional<std::pair<Pos, const Object*>> LeafNode::hit(const Ray& ray) const noexcept {
+    const auto p = m_object->hitRay(ray);
+    if (!p) return std::nullopt;
+    return std::pair<Pos, const Object*>{*p, m_object};
+}
+
+Tree::Tree(std::vector<const Object*> objects) : m_root(makeTree(std::move(objects), 0.5f)) {}
+
+std::optional<std::pair<Pos, const Object*>> Tree::hit(const Ray& ray) const noexcept {
+    if (!m_root) return std::nullopt;   // the reference dereferences a null root here
+    return m_root->hit(ray);
+}
+
+// The reference searches every (object, axis) split with an O(n^2) cost scan per level; because
+// traversal never culls, the topology only decides how exact ties are broken.  A split in the middle
+// of the insertion order keeps that order (ties go to the earlier object) and builds in O(n).
+std::unique_ptr<Node> Tree::makeTree(std::vector<const Object*> objects, float cost) {
+    if (objects.empty()) return nullptr;
+    if (objects.size() == 1) return std::make_unique<LeafNode>(objects[0]);
+    const auto mid = objects.begin() + static_cast<std::ptrdiff_t>(objects.size() / 2);
+    return std::make_unique<InternalNode>(makeTree(std::vector<const Object*>(objects.begin(), mid), cost),
+                                          makeTree(std::vector<const Object*>(mid, objects.end()), cost));
+}
+
+}   // namespace ObjectTree
+
+// ================================================================================================
+// GPU context shared by Renderer, Scene uploads and the tone mappers
+// ================================================================================================
+namespace mipt_host {
+
+[[noreturn]] void fail(const char* what, int status) {
+    std::fprintf(stderr, "pathtracer: %s: %s (status %d). The render path runs on the GPU only; there is no CPU fallback.\n", what,
+                 mipt_strerror(status), status);
+    std::abort();
+}
+
+mipt_ctx* shared_context() {
+    static std::mutex m;
+    static mipt_ctx* ctx = nullptr;
+    std::lock_guard<std::mutex> lock(m);
+    if (!ctx) {
+        int device = 0;
+        if (const char* e = std::getenv("MIPT_DEVICE")) device = std::atoi(e);
+        const int rc = mipt_init(device, nullptr, &ctx);
+        if (rc != MIPT_OK) fail("mipt_init", rc);
+    }
+    return ctx;
+}
+
+struct SceneDeviceState {
+    mipt_scene* scene = nullptr;
+    std::vector<uint32_t> kind, material;
+    std::vector<float> fwd, inv, params, materials;
+    float noise[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    ~SceneDeviceState() {
+        if (scene) mipt_scene_free(scene);
+    }
+};
+
+struct RendererState {
+    std::mutex mutex;
+    std::uint64_t seed = 0x5eed;
+    std::uint64_t frame = 0;
+    bool started = false;
+};
+
+// Flattens the objects (Scene::updateGeometry's job in this design) and uploads when anything changed.
+mipt_scene* sync_scene(const Scene& scene) {
+    SceneDeviceState& st = scene.deviceState();
+    const auto& objs = scene.objects();
+    const std::size_t n = objs.size();
+    if (n == 0) fail("Renderer::render: the scene has no objects", MIPT_ERR_ARGUMENT);
+    std::vector<uint32_t> kind(n), material(n);
+    std::vector<float> fwd(12 * n), inv(12 * n), params(9 * n), materials(14 * n);
+    bool any_sdf = false;
+    const float* own_noise = nullptr;
+    for (std::size_t i = 0; i < n; ++i) {
+        DevicePrimitive d;
+        objs[i]->describeForDevice(d);
+        if (d.kind < 0 || !d.material) {
+            std::fprintf(stderr,
+                         "pathtracer: object %zu (type %s) has no device counterpart: supported are SphereObject, BoxObject, TriangleObject, the demo's "
+                         "CraterBallObject and SDF classes that specialise mipt_host::DeviceSdf.\n",
+                         i, d.type_name);
+            std::abort();
+        }
+        kind[i] = static_cast<uint32_t>(d.kind);
+        any_sdf |= d.kind == MIPT_CRATERBALL;
+        if (d.noise && !own_noise) own_noise = d.noise;
+        material[i] = static_cast<uint32_t>(i);
+        affine_to(objs[i]->transformation(), &fwd[12 * i]);
+        affine_to(objs[i]->inverseTransformation(), &inv[12 * i]);
+        std::memcpy(&params[9 * i], d.params, sizeof(d.params));
+        std::memcpy(&materials[14 * i], d.material->record(), 14 * sizeof(float));
+    }
+    float noise[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    if (own_noise) {
+        std::memcpy(noise, own_noise, sizeof(noise));   // one noise transform per scene: the first CraterBall's
+    } else if (any_sdf) {
+        if (!&noiseTransform) {
+            std::fprintf(stderr, "pathtracer: the scene holds a crater ball but the program defines no noiseTransform()\n");
+            std::abort();
+        }
+        affine_to(noiseTransform(), noise);
+    }
+    const bool same = st.scene && kind == st.kind && material == st.material && fwd == st.fwd && inv == st.inv && params == st.params &&
+                      materials == st.materials && std::memcmp(noise, st.noise, sizeof(noise)) == 0;
+    if (same) return st.scene;
+    if (st.scene) {
+        mipt_scene_free(st.scene);
+        st.scene = nullptr;
+    }
+    mipt_scene_desc desc{};
+    desc.n_prims = static_cast<uint32_t>(n);
+    desc.kind = kind.data();
+    desc.fwd = fwd.data();
+    desc.inv = inv.data();
+    desc.params = params.data();
+    desc.material = material.data();
+    desc.n_materials = static_cast<uint32_t>(n);
+    desc.materials = materials.data();
+    desc.noise_transform = noise;
+    const int rc = mipt_scene_upload(shared_context(), &desc, &st.scene);
+    if (rc != MIPT_OK) fail("mipt_scene_upload", rc);
+    st.kind = std::move(kind);
+    st.material = std::move(material);
+    st.fwd = std::move(fwd);
+    st.inv = std::move(inv);
+    st.params = std::move(params);
+    st.materials = std::move(materials);
+    std::memcpy(st.noise, noise, sizeof(noise));
+    return st.scene;
+}
+
+}   // namespace mipt_host
+
+// ================================================================================================
+// scene (src/Scene.cpp)
+// ================================================================================================
+Scene::Scene() : m_objectTree(std::vector<const Object*>{}), m_device(std::make_unique<mipt_host::SceneDeviceState>()) {}
+Scene::~Scene() = default;
+Scene::Scene(Scene&&) noexcept = default;
+Scene& Scene::operator=(Scene&&) noexcept = default;
+
+void Scene::addObject(std::unique_ptr<Object> object) noexcept { m_objects.push_back(std::move(object)); }
+
+Color Scene::trace(Ray ray, std::size_t depth) const noexcept {   // :18-78
+    Color color;
+    Color att(1.0f, 1.0f, 1.0f);
+    for (std::size_t i = 0; i < depth; ++i) {
+        const auto hit = m_objectTree.hit(ray);
+        if (!hit) return color;
+        ray.pos = hit->first;
+        const ColorBounce b = hit->second->deflectRay(ray);
+        ray.pos += 1e-3f * b.rayDirection;
+        color.r += b.emitted.r * att.r;
+        color.g += b.emitted.g * att.g;
+        color.b += b.emitted.b * att.b;
+        att.r *= b.attenuation.r;
+        att.g *= b.attenuation.g;
+        att.b *= b.attenuation.b;
+        ray.dir = b.rayDirection;
+        if (att.r + att.b + att.g < 1e-6f) return color;
+    }
+    return color;
+}
+
+void Scene::updateGeometry() {   // :80-87
+    std::vector<const Object*> v;
+    v.reserve(m_objects.size());
+    for (const auto& o : m_objects) v.push_back(o.get());
+    m_objectTree = ObjectTree::Tree{std::move(v)};
+}
+
+// ================================================================================================
+// camera, settings, image
+// ================================================================================================
+Camera::Camera(Affine transform, float aspectRatio, float fieldOfView) noexcept
+    : m_transform(transform), m_aspectRatio(aspectRatio), m_fieldOfView(fieldOfView), m_focalDistance(10.0f), m_focalBlurRadius(0.0f) {}
+void Camera::setAspectRatio(float r) noexcept { m_aspectRatio = r; }
+void Camera::setFieldOfView(float f) noexcept { m_fieldOfView = f; }
+void Camera::setFocalDistance(float d) noexcept { m_focalDistance = d; }
+void Camera::setFocalBlurRadius(float r) noexcept { m_focalBlurRadius = r; }
+
+Ray Camera::getViewRay(float screenX, float screenY) const noexcept {   // src/Camera.cpp:65-81
+    const float x = screenX * 2.0f - 1.0f, y = screenY * 2.0f - 1.0f;
+    const Pos sp = m_aspectRatio > 1.0f ? Pos(x, y / m_aspectRatio) : Pos(x * m_aspectRatio, y);
+    const auto [rx, ry] = randomPointInCircle();
+    const float blurRad = m_focalBlurRadius * std::max(m_aspectRatio, 1.0f / m_aspectRatio);
+    const Vec blur(rx * blurRad, ry * blurRad, 0.0f);
+    const float fovScale = std::tan(m_fieldOfView * 3.141592654f / 180.0f);
+    const Vec view = Vec(fovScale * sp.x, fovScale * sp.y, 1.0f) + (blur / m_focalDistance);
+    return Ray((m_transform * view).unit(), m_transform * (sp - blur));
+}
+
+RenderSettings::RenderSettings(std::size_t w, std::size_t h) noexcept : m_width(w), m_height(h), m_numBounces(8), m_samplesPerPixel(1) {}
+void RenderSettings::setSize(size_t w, size_t h) noexcept { m_width = w; m_height = h; }
+void RenderSettings::setNumBounces(std::size_t n) noexcept { m_numBounces = n; }
+void RenderSettings::setSamplesPerPixel(std::size_t s) noexcept { m_samplesPerPixel = s; }
+
+Image::Image(std::size_t w, std::size_t h) : m_width(w), m_height(h), m_data(w * h, Color{}) {}
+
+void Image::save(const std::string& path) const {   // src/Image.cpp:48-60
+    std::ofstream f(path, std::ios::out | std::ios::binary);
+    const std::uint64_t w = m_width, h = m_height;
+    f.write(reinterpret_cast<const char*>(&w), sizeof(w));
+    f.write(reinterpret_cast<const char*>(&h), sizeof(h));
+    f.write(reinterpret_cast<const char*>(raw()), static_cast<std::streamsize>(m_data.size() * sizeof(Color)));
+}
+
+Image Image::load(const std::string& path) {   // :62-81
+    std::ifstream f(path, std::ios::in | std::ios::binary);
+    if (!f) throw std::runtime_error("Failed to open file: \"" + path + "\"");
+    std::uint64_t w = 0, h = 0;
+    f.read(reinterpret_cast<char*>(&w), sizeof(w));
+    f.read(reinterpret_cast<char*>(&h), sizeof(h));
+    Image img(w, h);
+    f.read(reinterpret_cast<char*>(img.raw()), static_cast<std::streamsize>(img.m_data.size() * sizeof(Color)));
+    return img;
+}
+
+void Image::fill(const Color& c) noexcept { std::fill(m_data.begin(), m_data.end(), c); }
+
+Image& Image::operator+=(const Image& other) noexcept {
+    for (size_t i = 0; i < m_data.size(); ++i) m_data[i] += other.m_data[i];
+    return *this;
+}
+
+// ================================================================================================
+// renderer (src/Renderer.cpp)
+// ================================================================================================
+Renderer::Renderer() noexcept : m_state(new (std::nothrow) mipt_host::RendererState) {}
+Renderer::~Renderer() = default;
+
+void Renderer::startThreadPool(size_t) {
+    mipt_host::shared_context();
+    m_state->started = true;
+}
+void Renderer::stopThreadPool() { m_state->started = false; }
+
+Image Renderer::render(const Scene& scene, const Camera& camera, const RenderSettings& settings) {
+    std::lock_guard<std::mutex> lock(m_state->mutex);
+    mipt_ctx* ctx = mipt_host::shared_context();
+    mipt_scene* dev = mipt_host::sync_scene(scene);
+    mipt_camera cam{};
+    affine_to(camera.transform(), cam.transform);
+    cam.aspect = camera.aspectRatio();
+    cam.fov_degrees = camera.fieldOfView();
+    cam.focal_distance = camera.focalDistance();
+    cam.blur_radius = camera.focalBlurRadius();
+    mipt_settings st{};
+    st.width = static_cast<uint32_t>(settings.width());
+    st.height = static_cast<uint32_t>(settings.height());
+    st.bounces = static_cast<uint32_t>(settings.numBounces());
+    st.spp = static_cast<uint32_t>(settings.samplesPerPixel());
+    st.seed = m_state->seed;
+    st.first_sample = static_cast<uint32_t>(m_state->frame * settings.samplesPerPixel());
+    m_state->frame += 1;
+    Image img(settings.width(), settings.height());
+    const int rc = mipt_render(ctx, dev, &cam, &st, img.raw(), nullptr);
+    if (rc != MIPT_OK && rc != MIPT_ERR_CANCELLED) mipt_host::fail("mipt_render", rc);
+    return img;
+}
+
+void Renderer::cancelRender() noexcept { mipt_cancel(mipt_host::shared_context()); }
+
+void Renderer::setSeed(std::uint64_t seed) noexcept {
+    m_state->seed = seed;
+    m_state->frame = 0;
+}
+
+// ================================================================================================
+// tone mappers (src/ToneMapper.cpp), on the GPU
+// ================================================================================================
+namespace {
+Image tonemap(int kind, const Image& img) noexcept {
+    Image out(img.width(), img.height());
+    const int rc = mipt_tonemap(mipt_host::shared_context(), kind, img.raw(), out.raw(), img.width(), img.height());
+    if (rc != MIPT_OK) mipt_host::fail("mipt_tonemap", rc);
+    return out;
+}
+}   // namespace
+
+Image ReinhardToneMapper::operator()(const Image& img) const noexcept { return tonemap(0, img); }
+Image FilmicToneMapper::operator()(const Image& img) const noexcept { return tonemap(1, img); }

@@ -200,6 +200,28 @@ class RefBackend:
         return sc.render(cam, w, h, bounces, spp, seed, threads=1)
 
 
+class HostApiBackend(RefBackend):
+    """This repository's C++ host API behind the same harness (pathtracer_amd/lib/libhost_harness.so, or
+    the build that carries the reference demo's SDF block).  Without a GPU the cases that go through
+    Renderer::render or the tone mappers are left out."""
+    name = "host-api"
+
+    def __init__(self, host, noise, gpu):
+        self.api = host
+        self.gpu = gpu
+        self.noise = np.asarray(noise, np.float32)
+        host.set_noise(self.noise)
+
+    def noise_fn(self, pos):
+        return self.api.noise(pos) if self.api.has("ref_noise") else None
+
+    def render(self, sc, cam, w, h, bounces, spp, seed):
+        return None   # the GPU renderer draws from its own generator: compared statistically elsewhere
+
+    def tonemap(self, kind, img):
+        return self.api.tonemap(kind, img) if self.gpu else None
+
+
 class OracleBackend:
     name = "oracle"
 
@@ -301,8 +323,9 @@ def evaluate(be, inp, heavy=True):
                                for i, m in enumerate(inp["deflect_mats"])])
 
     # tone mappers and the image file format
-    out["tonemap_reinhard"] = api.tonemap(0, inp["hdr"])
-    out["tonemap_filmic"] = api.tonemap(1, inp["hdr"])
+    tonemap = getattr(be, "tonemap", api.tonemap)   # a backend without a GPU returns None here
+    out["tonemap_reinhard"] = tonemap(0, inp["hdr"])
+    out["tonemap_filmic"] = tonemap(1, inp["hdr"])
     out["image_bytes"] = np.frombuffer(api.image_bytes(inp["hdr"]), np.uint8).copy()
 
     # scenes: closest hit, primary-hit maps, traced rays, rendered images
@@ -340,4 +363,4 @@ def evaluate(be, inp, heavy=True):
         ccam = demo_closeup_camera(alg)
         out["demo_close_prim"], out["demo_close_t"] = sc.primary_hits(ccam, 48, 48)
         out["demo_close_render"] = be.render(sc, ccam, 32, 32, 8, 2, 25)
-    return out
+    return {k: v for k, v in out.items() if v is not None}   # None: the backend cannot compute the case
