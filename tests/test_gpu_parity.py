@@ -215,3 +215,42 @@ def test_cancel_and_errors(ctx, alg):
     ctx.cancel()                                   # a cancel before the call is cleared by the call
     img, st = ctx.render(ds, cam, 16, 16, 4, 2)
     assert st["paths"] == 16 * 16 * 2 and img.max() > 0
+
+
+def test_config3_100k_primitives_first_hits(ctx, alg, oracle):
+    """Config 3's scene (100,000 alternating spheres / Y-rotated boxes): closest hits of 2,048 camera rays
+    against a brute-force scan over every primitive (the reference's tree never culls, and cannot even be
+    built at this size)."""
+    flat = S.random_scene(alg, 100_000, seed=7)
+    cam = S.random_scene_camera(alg)
+    r = np.random.RandomState(12)
+    sx, sy = r.uniform(0, 1, 2048).astype(np.float32), r.uniform(0, 1, 2048).astype(np.float32)
+    d, o = oracle.camera_rays(cam, sx, sy, rng_mode=1, seed=1)
+    ds = ctx.upload(flat)
+    info = ds.info()
+    assert info["analytic"] == 100_000 and info["nodes"] == 99_999 and 17 <= info["depth"] <= 60
+    _, prim, t = ctx.trace_rays(ds, o, d, 1, seed=1, first_hit=True)
+    wp, wt, _ = oracle.scene(flat).closest_hit(o, d)
+    assert np.array_equal(wp, prim)
+    assert np.array_equal(wt[wp >= 0], t[wp >= 0])
+    assert (wp >= 0).mean() > 0.2
+
+
+def test_config5_mirrors_glass_emitters_16_bounces(ctx, alg, oracle):
+    """Config 5's material mix (mirrors, glass, diffuse + emitters) at 16 bounces on 900 primitives:
+    every path is followed through reflection, refraction and inside hits with shared random numbers."""
+    flat = S.random_scene(alg, 900, seed=9, radius_scale=7.0, glass_mirror_mix=True)
+    o, d = _random_rays(6000, 21, 12.0, 8.0)
+    osc = oracle.scene(flat)
+    want = osc.trace(o, d, 16, rng_mode=1, seed=5)
+    got, prim, t = ctx.trace_rays(ctx.upload(flat), o, d, 16, seed=5, first_hit=True)
+    wp, wt, _ = osc.closest_hit(o, d)
+    assert np.array_equal(wp, prim) and np.array_equal(wt[wp >= 0], t[wp >= 0])
+    close = np.all(np.abs(want - got) <= 1e-4 * np.maximum(1.0, np.abs(want)), axis=1)
+    assert close.mean() >= 0.995, close.mean()
+    assert (want.max(axis=1) > 0).mean() > 0.05
+    cam = S.random_scene_camera(alg, aspect=1.0)
+    wimg, wst = osc.render(cam, 48, 48, 16, 4, rng_mode=1, seed=2, threads=0, full_width=True)
+    gimg, gst = ctx.render(ctx.upload(flat), cam, 48, 48, 16, 4, seed=2)
+    assert abs(gst["rays"] - wst["rays"]) <= 2e-3 * wst["rays"] and wst["rays"] > 1.5 * wst["paths"]
+    assert (np.abs(wimg - gimg) <= 1e-4 * np.maximum(1.0, np.abs(wimg))).all(axis=2).mean() >= 0.99
