@@ -56,6 +56,7 @@ struct mipt_scene {
     void* d_nodes = nullptr;
     void* d_sdf = nullptr;
     void* d_oct = nullptr;
+    void* d_craters = nullptr;
     uint32_t n_nodes = 0, n_analytic = 0, n_sdf = 0;
     int depth = 0;
 };
@@ -187,11 +188,14 @@ struct StageTimer {
     }
 };
 
-// One sample batch: generate (or preloaded rays) -> bounce loop.  Leaves per-path radiance in pb.rad.
-void enqueue_bounces(mipt_ctx* c, const mipt_scene* sc, const BatchParams& bp, uint32_t bounces) {
+// The bounce loop of one sample batch over the live-path queue of bounce 0.  `first_done` says how far
+// the caller already took bounce 0: 0 = nothing, 1 = closest analytic hit found, 2 = SDF march done too.
+// Leaves per-path radiance in pb.rad (slots that never hit anything keep what the caller put there).
+void enqueue_bounces(mipt_ctx* c, const mipt_scene* sc, const BatchParams& bp, uint32_t bounces, int first_done) {
     for (uint32_t b = 0; b < bounces; ++b) {
-        { StageTimer t(c, MIPT_STAGE_EXTEND); launch_extend(c->stream, sc->dev, bp, c->pb, b, sc->depth); }
-        if (sc->n_sdf) { StageTimer t(c, MIPT_STAGE_SDF_MARCH); launch_sdf_march(c->stream, sc->dev, bp, c->pb, b); }
+        const int done = b == 0 ? first_done : 0;
+        if (done < 1) { StageTimer t(c, MIPT_STAGE_EXTEND); launch_extend(c->stream, sc->dev, bp, c->pb, b, sc->depth); }
+        if (sc->n_sdf && done < 2) { StageTimer t(c, MIPT_STAGE_SDF_MARCH); launch_sdf_march(c->stream, sc->dev, bp, c->pb, b); }
         { StageTimer t(c, MIPT_STAGE_SHADE); launch_shade(c->stream, sc->dev, bp, c->pb, b, bounces); }
         if (sc->n_sdf) { StageTimer t(c, MIPT_STAGE_SHADE_SDF); launch_shade_sdf(c->stream, sc->dev, bp, c->pb, b, bounces); }
     }
@@ -234,8 +238,9 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.flags = st->flags;
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
-        { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate(c->stream, cr, bp, c->pb); }
-        enqueue_bounces(c, sc, bp, st->bounces);
+        HIP_TRY(c, hipMemsetAsync(c->pb.rad, 0, sizeof(float4) * bp.n_slots, c->stream));   // paths that hit nothing stay black
+        { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate_extend(c->stream, cr, sc->dev, bp, c->pb, sc->depth); }
+        enqueue_bounces(c, sc, bp, st->bounces, 1);
         { StageTimer t(c, MIPT_STAGE_ACCUMULATE); launch_accumulate(c->stream, bp, c->pb, d_sum); }
         done += now;
         // keep at most a couple of batches queued so that cancellation stays responsive
@@ -425,6 +430,45 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     const uint32_t n_analytic = static_cast<uint32_t>(boxes.size());
     BvhResult bvh = build_bvh(std::move(boxes));
 
+    // Big craters of each crater ball (for_each_nearby_scattered_point at scale 2, PathTracerDemo.cpp:375-409):
+    // which lattice cells pass the shell test depends on the ball's offset alone.  The device evaluates the
+    // cells of a cube that covers the shell (|cell - offset| <= 2 + 0.3 + sqrt(0.1) < 3), with the very
+    // arithmetic the kernels use; the cells that pass are kept in lattice order.
+    std::vector<float> craters;
+    if (any_sdf) {
+        constexpr int kCube = 9;
+        constexpr size_t kCells = size_t(kCube) * kCube * kCube;
+        float* d_cells = nullptr;
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_cells), kCells * 12 * sizeof(float)));
+        std::vector<float> cells(kCells * 12);
+        for (const SdfBox& sb : sdf) {
+            PrimRec& r = prims[sb.prim];
+            int base[3];
+            for (int a = 0; a < 3; ++a) {
+                if (!(std::fabs(r.p[a]) < 4.0e6f)) {   // lattice coordinates must stay exact 24-bit integers
+                    (void)hipFree(d_cells);
+                    return MIPT_ERR_ARGUMENT;
+                }
+                base[a] = static_cast<int>(std::floor(r.p[a])) - 4;
+            }
+            launch_crater_cells(c->stream, r.p, base, kCube, d_cells);
+            hipError_t ce = hipMemcpyAsync(cells.data(), d_cells, cells.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+            if (ce == hipSuccess) ce = hipStreamSynchronize(c->stream);
+            if (ce != hipSuccess) {
+                (void)hipFree(d_cells);
+                c->last_hip = static_cast<int>(ce);
+                return MIPT_ERR_HIP;
+            }
+            const uint32_t first = static_cast<uint32_t>(craters.size() / 12);
+            for (size_t i = 0; i < kCells; ++i)
+                if (cells[12 * i + 10] != 0.0f) craters.insert(craters.end(), cells.begin() + 12 * i, cells.begin() + 12 * i + 12);
+            const uint32_t count = static_cast<uint32_t>(craters.size() / 12) - first;
+            std::memcpy(&r.p[3], &first, 4);
+            std::memcpy(&r.p[4], &count, 4);
+        }
+        (void)hipFree(d_cells);
+    }
+
     auto* s = new (std::nothrow) mipt_scene;
     if (!s) return MIPT_ERR_OUT_OF_MEMORY;
     s->device = c->device;
@@ -465,6 +509,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
             std::memcpy(bb, b2, sizeof(bb));
         }
         if (e == hipSuccess) e = upload(&s->d_oct, oct, sizeof(oct));
+        if (e == hipSuccess) e = upload(&s->d_craters, craters.data(), craters.size() * sizeof(float));
     }
     if (e != hipSuccess) {
         c->last_hip = static_cast<int>(e);
@@ -477,6 +522,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     s->dev.nodes = static_cast<const BvhNode*>(s->d_nodes);
     s->dev.sdf_boxes = static_cast<const SdfBox*>(s->d_sdf);
     s->dev.noise_oct = static_cast<const float*>(s->d_oct);
+    s->dev.craters = static_cast<const float*>(s->d_craters);
     s->dev.n_sdf = static_cast<uint32_t>(sdf.size());
     s->dev.n_prims = n;
     s->n_nodes = static_cast<uint32_t>(bvh.nodes.size());
@@ -491,7 +537,7 @@ void mipt_scene_free(mipt_scene* s) {
     if (!s) return;
     // hipFree waits for work that still uses the memory; the context may already be gone
     (void)hipSetDevice(s->device);
-    for (void* p : {s->d_prims, s->d_tri, s->d_mats, s->d_nodes, s->d_sdf, s->d_oct})
+    for (void* p : {s->d_prims, s->d_tri, s->d_mats, s->d_nodes, s->d_sdf, s->d_oct, s->d_craters})
         if (p) (void)hipFree(p);
     delete s;
 }
@@ -552,8 +598,8 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     mipt_camera c0 = *cam;
     c0.blur_radius = 0.0f;
     HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
-    launch_generate(c->stream, pack_camera(c0), bp, c->pb);
-    launch_extend(c->stream, sc->dev, bp, c->pb, 0, sc->depth);
+    HIP_TRY(c, hipMemsetAsync(c->pb.hit_key, 0xff, n * 8, c->stream));   // the fused kernel stores hits only
+    launch_generate_extend(c->stream, pack_camera(c0), sc->dev, bp, c->pb, sc->depth);
     if (sc->n_sdf) launch_sdf_march(c->stream, sc->dev, bp, c->pb, 0);
     std::vector<unsigned long long> keys(n);
     HIP_TRY(c, hipMemcpyAsync(keys.data(), c->pb.hit_key, n * 8, hipMemcpyDeviceToHost, c->stream));
@@ -599,9 +645,8 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
         if (sc->n_sdf) launch_sdf_march(c->stream, sc->dev, bp, c->pb, 0);
         keys.resize(n);
         HIP_TRY(c, hipMemcpyAsync(keys.data(), c->pb.hit_key, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
     }
-    enqueue_bounces(c, sc, bp, bounces);
+    enqueue_bounces(c, sc, bp, bounces, keys.empty() ? 0 : 2);
     launch_export_rad(c->stream, c->pb, n, c->stage);
     HIP_TRY(c, hipMemcpyAsync(out_rgb, c->stage, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -9,7 +9,7 @@ namespace mipt {
 struct alignas(128) PrimRec {
     float inv[12];      // world -> local  (Object::m_inverseTransformation)
     float fwd[12];      // local -> world  (Object::m_transformation)
-    float p[6];         // sphere {r}; box {hx,hy,hz}; crater ball {offset}; triangle {a, b} (c in tri_c)
+    float p[6];         // sphere {r}; box {hx,hy,hz}; crater ball {offset, first crater, craters}; triangle {a, b} (c in tri_c)
     uint32_t kind;
     uint32_t material;
 };
@@ -61,6 +61,9 @@ struct SceneDev {
     // noise() (PathTracerDemo.cpp:56-70) unrolled: octave i samples A_i p + b_i with weight k_i; 13 floats per octave (A row-major,
     // b, k), 8 octaves (null when the scene has no SDF primitive)
     const float* noise_oct;
+    // big craters of every crater ball: 12 floats per crater {cell.xyz, size, on_sphere.xyz, t, age bits, 1/(5 size), -, -};
+    // a ball's records start at record PrimRec::p[3] and number PrimRec::p[4] (both uint32 bit patterns)
+    const float* craters;
 };
 
 // Per-bounce queue counters of one sample batch, zeroed once per batch.

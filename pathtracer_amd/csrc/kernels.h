@@ -32,8 +32,11 @@ struct BatchParams {
     uint64_t seed;
 };
 
-void launch_generate(hipStream_t, const CameraRec&, const BatchParams&, const PathBuffers&);
+// generate + first extend fused; needs counters zeroed; fills queue[0] and the SDF queue of bounce 0
+void launch_generate_extend(hipStream_t, const CameraRec&, const SceneDev&, const BatchParams&, const PathBuffers&, int bvh_depth);
 void launch_extend(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, int bvh_depth);
+// big-crater candidates of a crater ball: 12 floats per cell of the n^3 lattice cube at `base` (x-major)
+void launch_crater_cells(hipStream_t, const float off[3], const int base[3], int n, float* out);
 void launch_sdf_march(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce);
 void launch_shade(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, uint32_t max_bounces);
 void launch_shade_sdf(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, uint32_t max_bounces);

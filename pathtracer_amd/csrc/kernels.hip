@@ -286,143 +286,190 @@ __device__ __forceinline__ bool slab(f3 o, f3 inv_d, const float* lo, const floa
 }
 
 // =============================================================================================
-// generate: Renderer::doWork's sample set-up (src/Renderer.cpp:72-94) + Camera::getViewRay
-// (src/Camera.cpp:65-81).  One thread per path slot; slot = sample_in_batch * n_pix + pixel, so a wave
-// covers 64 neighbouring pixels of one sample and every store is a coalesced 1 KiB line.
+// Camera ray of one path slot: Renderer::doWork's sample set-up (src/Renderer.cpp:72-94) +
+// Camera::getViewRay (src/Camera.cpp:65-81).  slot = sample_in_batch * n_pix + pixel, so a wave covers
+// 64 neighbouring pixels of one sample.
 // =============================================================================================
-__global__ void __launch_bounds__(256) k_generate(CameraRec cam, BatchParams bp, PathBuffers pb) {
-    const uint32_t stride = gridDim.x * blockDim.x;
+__device__ __forceinline__ void camera_ray(const CameraRec& cam, const BatchParams& bp, uint32_t slot, f3& pos, f3& dir) {
     const float max_w = static_cast<float>(bp.width - 1), max_h = static_cast<float>(bp.height - 1);
     const float dx = 1.0f / max_w, dy = 1.0f / max_h;
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < bp.n_slots; slot += stride) {
-        const uint32_t s_local = slot / bp.n_pix;
-        const uint32_t pix = slot - s_local * bp.n_pix;
-        const uint32_t y = pix / bp.width, x = pix - y * bp.width;
-        Rng rng(bp.seed, pix, bp.first_sample + s_local, 0u);
-        float sx = static_cast<float>(x) / max_w;
-        float sy = static_cast<float>(y) / max_h;
-        if (!(bp.flags & 1u)) {
-            sx = sx + rng.uniform(-0.5f * dx, 0.5f * dx);
-            sy = sy + rng.uniform(-0.5f * dy, 0.5f * dy);
-        }
-        const float vx = sx * 2.0f - 1.0f;
-        const float vy = sy * 2.0f - 1.0f;
-        const f3 sp = cam.aspect > 1.0f ? mk3(vx, vy / cam.aspect, 0.0f) : mk3(vx * cam.aspect, vy, 0.0f);
-        float rx = 0.0f, ry = 0.0f;
-        if (cam.blur_rad != 0.0f) {   // randomPointInCircle src/Geometry.cpp:278-288 (draws k = 2, 3, ...)
-            rng.ctr = 3u;
-            do {
-                rx = rng.uniform(-1.0f, 1.0f);
-                ry = rng.uniform(-1.0f, 1.0f);
-            } while (rx * rx + ry * ry > 1.0f);
-        }
-        const f3 blur = mk3(rx * cam.blur_rad, ry * cam.blur_rad, 0.0f);
-        const f3 view = mk3(cam.fov_scale * sp.x, cam.fov_scale * sp.y, 1.0f) + blur * cam.inv_focal;
-        const f3 dir = unit(lin_mul(cam.lin, view));
-        const f3 l = lin_mul(cam.lin, sp - blur);
-        const f3 pos = mk3(l.x + cam.tr[0], l.y + cam.tr[1], l.z + cam.tr[2]);
-        pb.ray_o[slot] = st4(pos);
-        pb.ray_d[slot] = st4(dir);
-        pb.att[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        pb.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t s_local = slot / bp.n_pix;
+    const uint32_t pix = slot - s_local * bp.n_pix;
+    const uint32_t y = pix / bp.width, x = pix - y * bp.width;
+    Rng rng(bp.seed, pix, bp.first_sample + s_local, 0u);
+    float sx = static_cast<float>(x) / max_w;
+    float sy = static_cast<float>(y) / max_h;
+    if (!(bp.flags & 1u)) {
+        sx = sx + rng.uniform(-0.5f * dx, 0.5f * dx);
+        sy = sy + rng.uniform(-0.5f * dy, 0.5f * dy);
     }
+    const float vx = sx * 2.0f - 1.0f;
+    const float vy = sy * 2.0f - 1.0f;
+    const f3 sp = cam.aspect > 1.0f ? mk3(vx, vy / cam.aspect, 0.0f) : mk3(vx * cam.aspect, vy, 0.0f);
+    float rx = 0.0f, ry = 0.0f;
+    if (cam.blur_rad != 0.0f) {   // randomPointInCircle src/Geometry.cpp:278-288 (draws k = 2, 3, ...)
+        rng.ctr = 3u;
+        do {
+            rx = rng.uniform(-1.0f, 1.0f);
+            ry = rng.uniform(-1.0f, 1.0f);
+        } while (rx * rx + ry * ry > 1.0f);
+    }
+    const f3 blur = mk3(rx * cam.blur_rad, ry * cam.blur_rad, 0.0f);
+    const f3 view = mk3(cam.fov_scale * sp.x, cam.fov_scale * sp.y, 1.0f) + blur * cam.inv_focal;
+    dir = unit(lin_mul(cam.lin, view));
+    const f3 l = lin_mul(cam.lin, sp - blur);
+    pos = mk3(l.x + cam.tr[0], l.y + cam.tr[1], l.z + cam.tr[2]);
 }
 
 // =============================================================================================
-// extend: closest hit over the analytic primitives (ObjectTree::Tree::hit, src/ObjectTree.cpp:22-88,
-// with real culling) and the SDF boxes.  One lane per live ray; the traversal stack is a column of LDS
-// dwords per lane (entry e of lane l at e * blockDim + l: conflict-free for ds_read/write_b32).
+// Closest hit over the analytic primitives: ObjectTree::Tree::hit (src/ObjectTree.cpp:22-88) with real
+// culling.  The traversal stack is a column of LDS dwords per lane (entry e of lane l at
+// e * blockDim + l: conflict-free for ds_read/write_b32).  Hits are ranked by t = (hit - o).d as the
+// reference ranks them; boxes are culled in ray-parameter units, t / |d|^2, with a relative and an
+// absolute margin.  Returns the cull limit for the SDF box tests that follow.
+// =============================================================================================
+__device__ __forceinline__ float closest_analytic(const SceneDev& sc, int* stack, f3 o, f3 d, f3 inv_d, unsigned long long& best, f3& best_pos) {
+    const float inv_len2 = 1.0f / norm_sq(d);
+    float limit = 3.0e38f;
+    best = kMissKey;
+    best_pos = mk3(0.0f, 0.0f, 0.0f);
+    if (!sc.nodes) return limit;
+    int sp = 0;
+    int cur = 0;
+    for (;;) {
+        const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
+        const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+        const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y};
+        const float lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
+        int c0 = __float_as_int(e.x), c1 = __float_as_int(e.y);
+        float t0, t1;
+        bool h0 = slab(o, inv_d, lo0, hi0, limit, t0);
+        bool h1 = slab(o, inv_d, lo1, hi1, limit, t1);
+        if (h0 && h1 && t1 < t0) {   // nearer child first
+            const int tc = c0; c0 = c1; c1 = tc;
+            const float tt = t0; t0 = t1; t1 = tt;
+        } else if (!h0 && h1) {
+            c0 = c1; t0 = t1; h0 = true; h1 = false;
+        }
+        int next = -1;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const bool h = side == 0 ? h0 : h1;
+            const int ch = side == 0 ? c0 : c1;
+            const float tn = side == 0 ? t0 : t1;
+            if (!h || tn > limit) continue;
+            if (ch < 0) {
+                const uint32_t prim = static_cast<uint32_t>(~ch);
+                PrimRegs pr;
+                load_prim(sc.prims, prim, pr);
+                f3 w;
+                float t;
+                if (hit_analytic(pr, sc.tri_c, prim, o, d, w, t)) {
+                    const unsigned long long key = make_key(t, prim);
+                    if (key < best) {
+                        best = key;
+                        best_pos = w;
+                        limit = fmaxf(t, 0.0f) * inv_len2 * 1.00001f + 1e-6f;
+                    }
+                }
+            } else if (next < 0) {
+                next = ch;
+            } else {
+                stack[sp * 256] = ch;
+                ++sp;
+            }
+        }
+        if (next < 0) {
+            if (sp == 0) break;
+            --sp;
+            next = stack[sp * 256];
+        }
+        cur = next;
+    }
+    return limit;
+}
+
+// Does the ray reach any SDF primitive's box before its best analytic hit?
+__device__ __forceinline__ bool reaches_sdf_box(const SceneDev& sc, f3 o, f3 inv_d, float limit) {
+    bool any = false;
+    for (uint32_t k = 0; k < sc.n_sdf; ++k) {
+        float tn;
+        any = any || slab(o, inv_d, sc.sdf_boxes[k].lo, sc.sdf_boxes[k].hi, limit, tn);
+    }
+    return any;
+}
+
+// Appends `value` for the calling lanes (call it inside the branch that decided to append): one atomic
+// per wave, ranks by popcount of the lanes below.
+__device__ __forceinline__ void wave_append_active(uint32_t value, uint32_t* counter, uint32_t* queue) {
+    const unsigned long long m = __ballot(1);
+    const uint32_t lane = __lane_id();
+    const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+    uint32_t base = 0;
+    if (rank == 0) base = atomicAdd(counter, static_cast<uint32_t>(__popcll(m)));
+    base = __shfl(base, __ffsll(static_cast<long long>(m)) - 1);
+    queue[base + rank] = value;
+}
+
+// =============================================================================================
+// generate + first extend, fused: a primary ray lives in registers from the camera to its closest hit.
+// Only paths that hit an analytic primitive or reach an SDF box are written to HBM (ray, hit) and
+// queued for the stages that follow; on the demo scene that is ~5 % of the paths, the rest cost no
+// memory traffic at all.
+// =============================================================================================
+template <int STACK>
+__global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev sc, BatchParams bp, PathBuffers pb) {
+    __shared__ int s_stack[STACK * 256];
+    int* stack = s_stack + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t n_sdf_rays = 0;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < bp.n_slots; slot += stride) {
+        f3 o, d;
+        camera_ray(cam, bp, slot, o, d);
+        const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        unsigned long long best;
+        f3 best_pos;
+        const float limit = closest_analytic(sc, stack, o, d, inv_d, best, best_pos);
+        const bool wants_sdf = reaches_sdf_box(sc, o, inv_d, limit);
+        if (best != kMissKey || wants_sdf) {
+            pb.ray_o[slot] = st4(o);
+            pb.ray_d[slot] = st4(d);
+            pb.hit_key[slot] = best;
+            pb.hit_pos[slot] = st4(best_pos);
+            wave_append_active(slot, &pb.counters[0].n_live, pb.queue[0]);
+        }
+        if (wants_sdf) {
+            wave_append_active(slot, &pb.counters[0].n_sdf, pb.sdf_queue);
+            ++n_sdf_rays;
+        }
+    }
+    if (n_sdf_rays) atomicAdd(&pb.totals->sdf_rays, static_cast<unsigned long long>(n_sdf_rays));
+}
+
+// =============================================================================================
+// extend: closest hit for the rays of the live-path queue (bounces after the first, or rays loaded
+// from the host).  One lane per ray.
 // =============================================================================================
 template <int STACK>
 __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
     __shared__ int s_stack[STACK * 256];
-    const uint32_t n = bounce == 0 ? bp.n_slots : pb.counters[bounce].n_live;
-    const uint32_t* queue = bounce == 0 ? nullptr : pb.queue[bounce & 1];
+    const uint32_t n = pb.counters[bounce].n_live;
+    const uint32_t* queue = pb.queue[bounce & 1];
     const uint32_t stride = gridDim.x * blockDim.x;
     int* stack = s_stack + threadIdx.x;
     uint32_t n_sdf_rays = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t slot = queue ? queue[i] : i;
+        const uint32_t slot = queue[i];
         const f3 o = ld3(pb.ray_o[slot]);
         const f3 d = ld3(pb.ray_d[slot]);
         const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        // Hits are ranked by t = (hit - o).d as the reference ranks them; boxes are culled in
-        // ray-parameter units, t / |d|^2, with a relative and absolute margin.
-        const float inv_len2 = 1.0f / norm_sq(d);
-        unsigned long long best = kMissKey;
-        f3 best_pos = mk3(0.0f, 0.0f, 0.0f);
-        float limit = 3.0e38f;
-        if (sc.nodes) {
-            int sp = 0;
-            int cur = 0;
-            for (;;) {
-                const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
-                const float4 a = np[0], b = np[1], c = np[2], e = np[3];
-                const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y};
-                const float lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
-                int c0 = __float_as_int(e.x), c1 = __float_as_int(e.y);
-                float t0, t1;
-                bool h0 = slab(o, inv_d, lo0, hi0, limit, t0);
-                bool h1 = slab(o, inv_d, lo1, hi1, limit, t1);
-                if (h0 && h1 && t1 < t0) {   // nearer child first
-                    const int tc = c0; c0 = c1; c1 = tc;
-                    const float tt = t0; t0 = t1; t1 = tt;
-                } else if (!h0 && h1) {
-                    c0 = c1; t0 = t1; h0 = true; h1 = false;
-                }
-                int next = -1;
-#pragma unroll
-                for (int side = 0; side < 2; ++side) {
-                    const bool h = side == 0 ? h0 : h1;
-                    const int ch = side == 0 ? c0 : c1;
-                    const float tn = side == 0 ? t0 : t1;
-                    if (!h || tn > limit) continue;
-                    if (ch < 0) {
-                        const uint32_t prim = static_cast<uint32_t>(~ch);
-                        PrimRegs pr;
-                        load_prim(sc.prims, prim, pr);
-                        f3 w;
-                        float t;
-                        if (hit_analytic(pr, sc.tri_c, prim, o, d, w, t)) {
-                            const unsigned long long key = make_key(t, prim);
-                            if (key < best) {
-                                best = key;
-                                best_pos = w;
-                                limit = fmaxf(t, 0.0f) * inv_len2 * 1.00001f + 1e-6f;
-                            }
-                        }
-                    } else if (next < 0) {
-                        next = ch;
-                    } else {
-                        stack[sp * 256] = ch;
-                        ++sp;
-                    }
-                }
-                if (next < 0) {
-                    if (sp == 0) break;
-                    --sp;
-                    next = stack[sp * 256];
-                }
-                cur = next;
-            }
-        }
+        unsigned long long best;
+        f3 best_pos;
+        const float limit = closest_analytic(sc, stack, o, d, inv_d, best, best_pos);
         pb.hit_key[slot] = best;
         pb.hit_pos[slot] = st4(best_pos);
-        // Does the ray reach any SDF primitive's box before its best analytic hit?
-        bool wants_sdf = false;
-        for (uint32_t k = 0; k < sc.n_sdf; ++k) {
-            float tn;
-            wants_sdf = wants_sdf || slab(o, inv_d, sc.sdf_boxes[k].lo, sc.sdf_boxes[k].hi, limit, tn);
-        }
-        if (wants_sdf) {
-            // wave-aggregated append: one atomic per wave
-            const unsigned long long m = __ballot(1);
-            const uint32_t lane = __lane_id();
-            const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
-            uint32_t base = 0;
-            if (rank == 0) base = atomicAdd(&pb.counters[bounce].n_sdf, static_cast<uint32_t>(__popcll(m)));
-            base = __shfl(base, __ffsll(static_cast<long long>(m)) - 1);
-            pb.sdf_queue[base + rank] = slot;
+        if (reaches_sdf_box(sc, o, inv_d, limit)) {
+            wave_append_active(slot, &pb.counters[bounce].n_sdf, pb.sdf_queue);
             ++n_sdf_rays;
         }
     }
@@ -741,6 +788,213 @@ __device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, const 
     }
 }
 
+// =============================================================================================
+// The big craters of a ball do not depend on the query: a lattice cell passes the shell test or not,
+// and its point on the sphere, size, depth parameter and age follow from its hash alone.  They are
+// tabulated once per primitive (about 32 cells pass for any offset; three float4 per cell, lattice
+// order): {cell.xyz, size}, {on_sphere.xyz, t}, {age, 1 / (5 size), -, -}.
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_crater_cells(float ox, float oy, float oz, int bx, int by, int bz, int n, float4* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * n * n) return;
+    const int ix = i / (n * n), iy = (i / n) % n, iz = i % n;
+    const f3 off = mk3(ox, oy, oz);
+    const f3 g = mk3(static_cast<float>(bx + ix), static_cast<float>(by + iy), static_cast<float>(bz + iz));
+    uint32_t hash;
+    f3 on;
+    const f3 point = scattered_cell(g, 0.3f, hash);
+    const bool pass = project_cell(point, off, 2.0f, on);
+    const float t = static_cast<float>(hash & 0xffffu) * (1.0f / 65535.0f);
+    const float size = fmaf(0.4f * t, t, 0.05f);
+    out[3 * i] = make_float4(g.x, g.y, g.z, size);
+    out[3 * i + 1] = make_float4(on.x, on.y, on.z, t);
+    out[3 * i + 2] = make_float4(__uint_as_float(hash >> 16), fast_rcp(size * 5.0f), pass ? 1.0f : 0.0f, 0.0f);
+}
+
+// ---- lane-parallel near field: one point per lane -------------------------------------------------
+// When most lanes of a wave need a near-field value at once, the wave evaluates them side by side:
+// a wave-uniform loop over the primitive's crater table (records in scalar registers), the small and
+// tiny craters cell by cell, and only noise() stays cooperative -- every lane stages the arguments of
+// its calls in a ring in LDS, and rounds of 8 calls x 8 octaves drain the ring whenever half of it is
+// full, writing each value to the LDS slot its owner named.
+constexpr int kRing = 256;          // staged noise() arguments; one crater step adds at most 128
+constexpr int kLaneDeposits = 8;    // fallout deposits one lane can hold; a point with more is left to the caller
+constexpr int kLaneLdsFloats = 4 * kRing + 4 * 64 * kLaneDeposits + 2 * 64 + 8;
+constexpr int kNearLdsFloats = kLaneLdsFloats > kCoopLdsFloats ? kLaneLdsFloats : kCoopLdsFloats;   // per wave, either way of evaluating
+constexpr int kLaneThreshold = 24;   // lanes that must be waiting before the lane-parallel evaluation pays
+
+__device__ __forceinline__ void noise_ring_rounds(const CoopLane& cl, float* lds, uint32_t lane, uint32_t& done, uint32_t staged, bool flush_all) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float* rx = lds;
+    const float* ry = lds + kRing;
+    const float* rz = lds + 2 * kRing;
+    const uint32_t* rt = reinterpret_cast<const uint32_t*>(lds + 3 * kRing);
+    while (flush_all ? done < staged : done + 8u <= staged) {
+        const uint32_t call = done + (lane >> 3);
+        const uint32_t slot = call & (kRing - 1);
+        const float x = rx[slot], y = ry[slot], z = rz[slot];
+        const uint32_t target = rt[slot];
+        const float qx = fmaf(cl.A[0], x, fmaf(cl.A[1], y, fmaf(cl.A[2], z, cl.b[0])));
+        const float qy = fmaf(cl.A[3], x, fmaf(cl.A[4], y, fmaf(cl.A[5], z, cl.b[1])));
+        const float qz = fmaf(cl.A[6], x, fmaf(cl.A[7], y, fmaf(cl.A[8], z, cl.b[2])));
+        const float a = (fabsf(__builtin_amdgcn_fractf(qx + 0.25f) - 0.5f) + fabsf(__builtin_amdgcn_fractf(qy + 0.25f) - 0.5f)) +
+                        fabsf(__builtin_amdgcn_fractf(qz + 0.25f) - 0.5f);
+        float v = cl.k * a;
+        v += dpp_f<kQuadXor1>(0.0f, v);
+        v += dpp_f<kQuadXor2>(0.0f, v);
+        v += dpp_f<kRowHalfMirror>(0.0f, v);
+        if ((lane & 7u) == 0u && call < staged) lds[target] = fmaf(4.0f, v, -3.0f * 0.11390656f);
+        done += 8u;
+    }
+    if (done > staged) done = staged;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Evaluates the near field at `pos` for every lane with `active` set; all 64 lanes must call.  The
+// lanes' primitive (crater table, `count` records) is wave-uniform.  Returns false for a lane whose
+// point has more fallout deposits than a lane can hold; its `out` is then not written.
+__device__ __forceinline__ bool lane_near(const float4* __restrict__ craters, uint32_t count, const CoopLane& cl, float* lds, bool active, f3 pos,
+                                          f3 off, float s, uint32_t lane, float& out, uint32_t& noise_calls) {
+    float* rx = lds;
+    float* ry = lds + kRing;
+    float* rz = lds + 2 * kRing;
+    uint32_t* rt = reinterpret_cast<uint32_t*>(lds + 3 * kRing);
+    constexpr uint32_t kCol = 4 * kRing;                            // float4 {n1, n2, lin, depth} of deposit j of lane l at kCol + 4 (64 j + l)
+    constexpr uint32_t kFin = kCol + 4 * 64 * kLaneDeposits;        // the two final noise values of lane l at kFin + 2 l
+    const float il = fast_rsq(norm_sq(pos));
+    const f3 u = mk3(-pos.x * il, -pos.y * il, -pos.z * il);
+    const f3 query = mk3(fmaf(u.x, 2.0f, off.x), fmaf(u.y, 2.0f, off.y), fmaf(u.z, 2.0f, off.z));
+    const f3 fl = mk3(floorf(query.x) + 0.5f, floorf(query.y) + 0.5f, floorf(query.z) + 0.5f);
+    // the two final noise() calls of every active lane open the ring
+    const unsigned long long am = __ballot(active);
+    uint32_t staged = 2u * static_cast<uint32_t>(__popcll(am)), done = 0;
+    if (active) {
+        const uint32_t r = 2u * __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(am >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(am), 0u));
+        const f3 q = pos + off;
+        rx[r] = q.x * 20.0f;
+        ry[r] = q.y * 20.0f;
+        rz[r] = q.z * 20.0f;
+        rt[r] = kFin + 2u * lane;
+        rx[r + 1] = q.x * 1.5f;
+        ry[r + 1] = q.y * 1.5f;
+        rz[r + 1] = q.z * 1.5f;
+        rt[r + 1] = kFin + 2u * lane + 1u;
+    }
+    if (staged >= 128u) noise_ring_rounds(cl, lds, lane, done, staged, false);
+
+    // ---- big craters :375-409 from the table ---------------------------------------------------
+    float crater_big = 0.0f;
+    uint32_t min_age = 0xffffu, n_dep = 0;
+    bool overflow = false;
+    for (uint32_t c = 0; c < count; ++c) {
+        const float4 r0 = craters[3 * c], r1 = craters[3 * c + 1], r2 = craters[3 * c + 2];
+        // the cell lies in the query's 4^3 neighbourhood: cell - floor(query) in {-1, 0, 1, 2}
+        const bool in = active && fabsf(r0.x - fl.x) < 2.0f && fabsf(r0.y - fl.y) < 2.0f && fabsf(r0.z - fl.z) < 2.0f;
+        bool dep = false;
+        float a1x = 0, a1y = 0, a1z = 0, a2x = 0, a2y = 0, a2z = 0, lin = 0, depth = 0;
+        if (in) {
+            const float size = r0.w, t = r1.w;
+            const f3 on = mk3(r1.x, r1.y, r1.z);
+            const f3 qv = query - on;
+            const float dist2 = norm_sq(qv);
+            const float idist = fast_rsq(fmaxf(dist2, 1e-30f));
+            const float dist = dist2 * idist;
+            const float c20 = 20.0f * (dist - size);
+            const float th = fast_tanh(c20);
+            const float rim = 0.9f * t * th * c20 * fast_rcp(fmaf(c20 * c20, c20, 0.02f));
+            depth = c20 > 1e-3f ? rim : th;
+            const bool outside = dist >= size;
+            lin = fmaxf(0.0f, 1.2f - dist * r2.y);
+            crater_big += -0.02f * depth;
+            if (!outside) min_age = min(min_age, __float_as_uint(r2.x));
+            dep = outside && lin > 0.0f;
+            if (dep && n_dep >= static_cast<uint32_t>(kLaneDeposits)) {
+                overflow = true;
+                dep = false;
+            }
+            const float k1 = 3.0f * size * idist, k2 = 40.0f * size * idist;
+            a1x = fmaf(k1, qv.x, on.x);
+            a1y = fmaf(k1, qv.y, on.y);
+            a1z = fmaf(k1, qv.z, on.z);
+            a2x = fmaf(k2, qv.x, on.x);
+            a2y = fmaf(k2, qv.y, on.y);
+            a2z = fmaf(k2, qv.z, on.z);
+        }
+        const unsigned long long dm = __ballot(dep);
+        if (dm) {
+            if (dep) {
+                const uint32_t call = staged + 2u * __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(dm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(dm), 0u));
+                const uint32_t s0 = call & (kRing - 1), s1 = (call + 1u) & (kRing - 1);
+                const uint32_t col = kCol + 4u * (64u * n_dep + lane);
+                rx[s0] = a1x;
+                ry[s0] = a1y;
+                rz[s0] = a1z;
+                rt[s0] = col;
+                rx[s1] = a2x;
+                ry[s1] = a2y;
+                rz[s1] = a2z;
+                rt[s1] = col + 1u;
+                lds[col + 2] = lin;
+                lds[col + 3] = depth;
+                ++n_dep;
+            }
+            staged += 2u * static_cast<uint32_t>(__popcll(dm));
+            if (staged - done >= 128u) noise_ring_rounds(cl, lds, lane, done, staged, false);
+        }
+    }
+
+    // ---- small craters :412-437 and tiny craters :440-463, cell by cell in the reference's order ----
+    float crater_small = -3.402823466e38f, tiny = 0.0f;
+    if (active) {
+#pragma unroll 1
+        for (int pass_no = 0; pass_no < 2; ++pass_no) {
+            const float scale = pass_no == 0 ? 10.0f : 60.0f;
+            const f3 q2 = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
+            const f3 f2 = mk3(floorf(q2.x), floorf(q2.y), floorf(q2.z));
+#pragma unroll 1
+            for (int cell = 0; cell < 8; ++cell) {
+                uint32_t h2;
+                f3 on2;
+                const f3 pt2 = scattered_cell(mk3(f2.x + static_cast<float>(cell >> 2), f2.y + static_cast<float>((cell >> 1) & 1), f2.z + static_cast<float>(cell & 1)), 0.5f, h2);
+                const bool pass2 = project_cell(pt2, off, scale, on2);
+                const float t2 = static_cast<float>(h2 & 0xffffu) * (1.0f / 65535.0f);
+                const uint32_t age2 = h2 >> 16;
+                const float d2 = sqrtf(norm_sq(q2 - on2));
+                const float size2 = pass_no == 0 ? fmaf(0.35f * t2, t2, 0.05f) : fmaf(0.35f, t2, 0.02f);
+                const float c50 = 50.0f * (d2 - size2);
+                const float th = fast_tanh(c50);
+                if (pass_no == 0) {
+                    if (pass2 && c50 < 0.0f && age2 <= min_age) {
+                        crater_small = fmaxf(crater_small, -0.005f * th);
+                        min_age = age2;
+                    }
+                } else if (pass2 && age2 <= min_age) {
+                    tiny = fmaxf(tiny, -0.004f * size2 * (-0.5f + 0.5f * th));
+                }
+            }
+        }
+    }
+
+    // ---- remaining noise() calls, then fallout and the final sum ----------------------------------
+    noise_ring_rounds(cl, lds, lane, done, staged, true);
+    if (active && !overflow) {
+        float fallout = 0.0f;
+        for (uint32_t j = 0; j < n_dep; ++j) {
+            const float4 e = *reinterpret_cast<const float4*>(lds + kCol + 4u * (64u * j + lane));
+            const float falloff = fast_exp2((2.0f + 3.0f * e.x) * fast_log2(e.z));
+            fallout += 0.1f * falloff * (0.2f + 0.4f * e.w) * e.y;
+        }
+        const float nf1 = lds[kFin + 2u * lane], nf2 = lds[kFin + 2u * lane + 1u];
+        out = s + fmaxf(crater_big, crater_small) + tiny + fallout + 0.01f * nf1 + 0.4f * nf2;
+        noise_calls = 2u * n_dep + 2u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return !overflow;
+}
+
 #pragma clang fp contract(off)
 
 // Adds a per-lane counter into a 64-bit total with one atomic per wave.
@@ -792,15 +1046,15 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
     constexpr int IDLE = 0, SETUP = 1, MARCH = 2;
     int state = IDLE;
     bool exhausted = false;
-    uint32_t slot = 0, k = 0, prim = 0;
+    uint32_t slot = 0, k = 0, prim = 0, crater_base = 0, crater_count = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv_d = mk3(0, 0, 0), off = mk3(0, 0, 0), best_pos = mk3(0, 0, 0);
     float inv_len2 = 0.0f, limit = 0.0f;
     unsigned long long best = kMissKey;
     bool improved = false;
     uint32_t c_far = 0, c_near = 0, c_noise = 0;
-    __shared__ float s_coop[4 * kCoopLdsFloats];
+    __shared__ __attribute__((aligned(16))) float s_coop[4 * kNearLdsFloats];
     const uint32_t lane = __lane_id();
-    float* lds = s_coop + (threadIdx.x >> 6) * kCoopLdsFloats;
+    float* lds = s_coop + (threadIdx.x >> 6) * kNearLdsFloats;
     const CoopLane cl = make_coop_lane(sc.noise_oct, lane);
     March m;
     m.p = m.dir = mk3(0, 0, 0);
@@ -856,6 +1110,8 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
                 const f3 lo = aff_pos(pr->inv, o);
                 const f3 ld = lin_mul(pr->inv, d);
                 off = mk3(pr->p[0], pr->p[1], pr->p[2]);
+                crater_base = __float_as_uint(pr->p[3]);
+                crater_count = __float_as_uint(pr->p[4]);
                 bool ok = true;
                 f3 p0 = lo;
                 if (!inside_rect(lo, mk3(1.0f, 1.0f, 1.0f))) ok = hit_rect(lo, ld, mk3(1.0f, 1.0f, 1.0f), p0);   // intersect(ray, bb), box centred at 0
@@ -889,6 +1145,26 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
         const bool wants = state == MARCH && result == 0;
         unsigned long long need = __ballot(wants);
         float d2 = 0.0f;
+        if (__popcll(need) >= kLaneThreshold) {
+            // most lanes wait for a value: one point per lane, primitive by primitive
+            unsigned long long todo = need;
+            while (todo) {
+                const int first = __ffsll(static_cast<long long>(todo)) - 1;
+                const uint32_t base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(crater_base), first));
+                const uint32_t count = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(crater_count), first));
+                const bool mine = wants && crater_base == base;
+                float v = 0.0f;
+                uint32_t calls = 0;
+                const bool ok = lane_near(reinterpret_cast<const float4*>(sc.craters) + 3u * base, count, cl, lds, mine, m.p, off, s, lane, v, calls);
+                if (mine && ok) {
+                    d2 = v;
+                    c_noise += calls;
+                    ++c_near;
+                }
+                todo &= ~__ballot(mine);
+                need &= ~__ballot(mine && ok);
+            }
+        }
         while (__popcll(need) >= kCoopGroup) {
             int src[kCoopGroup];
             f3 P[kCoopGroup], O[kCoopGroup];
@@ -971,8 +1247,9 @@ __device__ __forceinline__ bool apply_bounce(const PathBuffers& pb, uint32_t slo
                                              uint32_t bounce, uint32_t max_bounces) {
     const f3 wdir = lin_mul(pr.fwd, b.dir);   // only the direction returns to world space (src/Object.cpp:42)
     const f3 npos = mk3(world_pos.x + 1e-3f * wdir.x, world_pos.y + 1e-3f * wdir.y, world_pos.z + 1e-3f * wdir.z);   // src/Scene.cpp:54
-    float4 att = pb.att[slot];
-    float4 rad = pb.rad[slot];
+    // a path starts with attenuation 1 and no radiance (src/Scene.cpp:19-20); neither is stored before the first hit
+    float4 att = bounce == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : pb.att[slot];
+    float4 rad = bounce == 0 ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : pb.rad[slot];
     rad.x += b.emitted.x * att.x;
     rad.y += b.emitted.y * att.y;
     rad.z += b.emitted.z * att.z;
@@ -990,8 +1267,8 @@ __device__ __forceinline__ bool apply_bounce(const PathBuffers& pb, uint32_t slo
 }
 
 __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce, uint32_t max_bounces) {
-    const uint32_t n = bounce == 0 ? bp.n_slots : pb.counters[bounce].n_live;
-    const uint32_t* queue = bounce == 0 ? nullptr : pb.queue[bounce & 1];
+    const uint32_t n = pb.counters[bounce].n_live;
+    const uint32_t* queue = pb.queue[bounce & 1];
     uint32_t* next_queue = pb.queue[(bounce + 1) & 1];
     const uint32_t stride = gridDim.x * blockDim.x;
     // all lanes of a wave run the same number of iterations so that the wave-wide ballots line up
@@ -1001,7 +1278,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
         bool alive = false, to_sdf = false;
         uint32_t slot = 0;
         if (i < n) {
-            slot = queue ? queue[i] : i;
+            slot = queue[i];
             const unsigned long long key = pb.hit_key[slot];
             if (key != kMissKey) {
                 const uint32_t prim = static_cast<uint32_t>(key & 0xffffffffu);
@@ -1138,7 +1415,7 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
 }
 
 __global__ void k_finish_batch(PathBuffers pb, uint32_t bounces, uint32_t n_slots) {
-    unsigned long long rays = n_slots;
+    unsigned long long rays = n_slots;   // every path casts its primary ray; later casts are the queue lengths
     for (uint32_t b = 1; b < bounces; ++b) rays += pb.counters[b].n_live;
     pb.totals->rays += rays;
 }
@@ -1171,8 +1448,9 @@ __global__ void __launch_bounds__(256) k_load_rays(const float* pos, const float
     if (i >= n) return;
     pb.ray_o[i] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], 0.0f);
     pb.ray_d[i] = make_float4(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2], 0.0f);
-    pb.att[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     pb.rad[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    pb.queue[0][i] = i;
+    if (i == 0) pb.counters[0].n_live = n;
 }
 
 __global__ void __launch_bounds__(256) k_export_rad(PathBuffers pb, uint32_t n, float* out) {
@@ -1279,8 +1557,12 @@ static inline uint32_t grid_for(size_t n, uint32_t cap = 256u * 32u) {
     return static_cast<uint32_t>(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
-void launch_generate(hipStream_t st, const CameraRec& cam, const BatchParams& bp, const PathBuffers& pb) {
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(bp.n_slots)), dim3(256), 0, st, cam, bp, pb);
+void launch_generate_extend(hipStream_t st, const CameraRec& cam, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, int bvh_depth) {
+    const dim3 grid(grid_for(bp.n_slots, 256u * 32u)), block(256);
+    if (bvh_depth <= 8) hipLaunchKernelGGL(k_generate_extend<8>, grid, block, 0, st, cam, sc, bp, pb);
+    else if (bvh_depth <= 24) hipLaunchKernelGGL(k_generate_extend<24>, grid, block, 0, st, cam, sc, bp, pb);
+    else if (bvh_depth <= 40) hipLaunchKernelGGL(k_generate_extend<40>, grid, block, 0, st, cam, sc, bp, pb);
+    else hipLaunchKernelGGL(k_generate_extend<64>, grid, block, 0, st, cam, sc, bp, pb);
 }
 
 void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, int bvh_depth) {
@@ -1289,6 +1571,10 @@ void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, co
     else if (bvh_depth <= 24) hipLaunchKernelGGL(k_extend<24>, grid, block, 0, st, sc, bp, pb, bounce);
     else if (bvh_depth <= 40) hipLaunchKernelGGL(k_extend<40>, grid, block, 0, st, sc, bp, pb, bounce);
     else hipLaunchKernelGGL(k_extend<64>, grid, block, 0, st, sc, bp, pb, bounce);
+}
+
+void launch_crater_cells(hipStream_t st, const float off[3], const int base[3], int n, float* out) {
+    hipLaunchKernelGGL(k_crater_cells, dim3((n * n * n + 255) / 256), dim3(256), 0, st, off[0], off[1], off[2], base[0], base[1], base[2], n, reinterpret_cast<float4*>(out));
 }
 
 void launch_sdf_march(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce) {
