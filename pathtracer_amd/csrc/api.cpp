@@ -37,6 +37,7 @@ struct mipt_ctx {
     float* tm_scratch = nullptr;     // Reinhard partials
     float* stage = nullptr;          // staging for probes / host tone mapping
     size_t stage_cap = 0;
+    uint32_t lane_threshold = 24;   // MIPT_LANE_THRESHOLD: 1 = always one point per lane, 65 = never
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // optional per-launch timing
@@ -236,6 +237,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.height = st->height;
         bp.first_sample = st->first_sample + done;
         bp.flags = st->flags;
+        bp.lane_threshold = c->lane_threshold;
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
         HIP_TRY(c, hipMemsetAsync(c->pb.rad, 0, sizeof(float4) * bp.n_slots, c->stream));   // paths that hit nothing stay black
@@ -309,6 +311,10 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
         hipMalloc(reinterpret_cast<void**>(&c->tm_scratch), reinhard_scratch_floats() * sizeof(float)) != hipSuccess) {
         mipt_shutdown(c);
         return MIPT_ERR_NO_DEVICE;
+    }
+    if (const char* e = std::getenv("MIPT_LANE_THRESHOLD")) {
+        const long v = std::atol(e);
+        if (v >= 1 && v <= 65) c->lane_threshold = static_cast<uint32_t>(v);
     }
     *out = c;
     return MIPT_OK;
@@ -463,6 +469,10 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
             for (size_t i = 0; i < kCells; ++i)
                 if (cells[12 * i + 10] != 0.0f) craters.insert(craters.end(), cells.begin() + 12 * i, cells.begin() + 12 * i + 12);
             const uint32_t count = static_cast<uint32_t>(craters.size() / 12) - first;
+            if (count > 64) {   // one crater per lane; the shell holds ~32 cells for any offset (23..39 seen)
+                (void)hipFree(d_cells);
+                return MIPT_ERR_TOO_LARGE;
+            }
             std::memcpy(&r.p[3], &first, 4);
             std::memcpy(&r.p[4], &count, 4);
         }
@@ -595,6 +605,7 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     bp.width = width;
     bp.height = height;
     bp.flags = MIPT_FLAG_NO_JITTER;
+    bp.lane_threshold = c->lane_threshold;
     mipt_camera c0 = *cam;
     c0.blur_radius = 0.0f;
     HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
@@ -635,6 +646,7 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     bp.n_pix = bp.n_slots = n;
     bp.width = n;
     bp.height = 1;
+    bp.lane_threshold = c->lane_threshold;
     bp.seed = seed;
     HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
     launch_load_rays(c->stream, c->stage, c->stage + static_cast<size_t>(n) * 3, n, c->pb);

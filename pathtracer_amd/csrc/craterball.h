@@ -1,0 +1,610 @@
+// CraterBallObject::signedDistance (PathTracerDemo.cpp:26-116, 361-466) for whole waves.  Included by
+// kernels.hip after its vector helpers.
+//
+// Two evaluators share every per-term formula below and agree bit for bit, so a point's value does
+// not depend on which of them served it (which lanes of which wave ask together is a matter of timing):
+//   * coop_near: all 64 lanes work on one point (or a group of 4) -- for waves with few points;
+//   * lane_near: one point per lane -- for waves where most lanes hold a point.
+// What makes them agree: floating-point contraction is off in this file and every fused multiply-add
+// is spelled fmaf; sums over craters are taken in fixed point (integer addition is associative);
+// everything else that crosses lanes is a minimum or a maximum.
+#pragma once
+
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+// tanh(c) = 1 - 2 / (exp(2c) + 1); absolute error ~1e-7, which is what the SDF terms it feeds need
+__device__ __forceinline__ float fast_tanh(float c) {
+    const float e = fast_exp2(c * 2.885390081777927f);   // 2 / ln 2
+    return fmaf(-2.0f, fast_rcp(e + 1.0f), 1.0f);
+}
+__device__ __forceinline__ float fnorm2(f3 v) { return fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)); }
+
+// ---- wave-wide reductions on the DPP crossbar (every lane must be active) --------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float identity, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t identity, uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(identity), static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kRowHalfMirror = 0x141, kRowMirror = 0x140, kRowBcast15 = 0x142, kRowBcast31 = 0x143;
+constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114;
+
+__device__ __forceinline__ int wave_sum_i(int x) {
+    uint32_t v = static_cast<uint32_t>(x);
+    v += dpp_u<kQuadXor1>(0u, v);
+    v += dpp_u<kQuadXor2>(0u, v);
+    v += dpp_u<kRowHalfMirror>(0u, v);
+    v += dpp_u<kRowMirror>(0u, v);
+    v += dpp_u<kRowBcast15, 0xa>(0u, v);
+    v += dpp_u<kRowBcast31, 0xc>(0u, v);
+    return __builtin_amdgcn_readlane(static_cast<int>(v), 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u(uint32_t v) {
+    v = min(v, dpp_u<kQuadXor1>(0xffffffffu, v));
+    v = min(v, dpp_u<kQuadXor2>(0xffffffffu, v));
+    v = min(v, dpp_u<kRowHalfMirror>(0xffffffffu, v));
+    v = min(v, dpp_u<kRowMirror>(0xffffffffu, v));
+    v = min(v, dpp_u<kRowBcast15, 0xa>(0xffffffffu, v));
+    v = min(v, dpp_u<kRowBcast31, 0xc>(0xffffffffu, v));
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+__device__ __forceinline__ float bcast_lane(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ uint32_t bcast_lane_u(uint32_t v, int lane) {
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), lane));
+}
+// row-wise (16 lanes) reductions: afterwards every lane of a row holds the row's result
+__device__ __forceinline__ float row_max(float v) {
+    const float ninf = -3.402823466e38f;
+    v = fmaxf(v, dpp_f<kQuadXor1>(ninf, v));
+    v = fmaxf(v, dpp_f<kQuadXor2>(ninf, v));
+    v = fmaxf(v, dpp_f<kRowHalfMirror>(ninf, v));
+    v = fmaxf(v, dpp_f<kRowMirror>(ninf, v));
+    return v;
+}
+__device__ __forceinline__ uint32_t row_min_u(uint32_t v) {
+    v = min(v, dpp_u<kQuadXor1>(0xffffffffu, v));
+    v = min(v, dpp_u<kQuadXor2>(0xffffffffu, v));
+    v = min(v, dpp_u<kRowHalfMirror>(0xffffffffu, v));
+    v = min(v, dpp_u<kRowMirror>(0xffffffffu, v));
+    return v;
+}
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Sums over craters are carried as integers of 2^-30: every term is below 0.03 in magnitude and at
+// most 64 craters contribute, so the sum stays below 2^31.
+constexpr float kFixScale = 1073741824.0f;
+__device__ __forceinline__ int to_fix(float v) { return static_cast<int>(v * kFixScale); }
+__device__ __forceinline__ float from_fix(int v) { return static_cast<float>(v) * (1.0f / kFixScale); }
+
+__device__ __forceinline__ uint32_t mul24_lo(int a, int k) {
+    int r;
+    asm("v_mul_i32_i24_e32 %0, %1, %2" : "=v"(r) : "s"(k), "v"(a));
+    return static_cast<uint32_t>(r);
+}
+__device__ __forceinline__ uint32_t shl5(uint32_t h) {
+    uint32_t r;
+    asm("v_lshlrev_b32_e32 %0, 5, %1" : "=v"(r) : "v"(h));
+    return r;
+}
+
+// One cell of for_each_nearby_scattered_point :79-116: hashed, jittered lattice point.  The reference
+// forms the jitter through double; fmaf(scatter/2, m, g) rounds the same exact value once.
+__device__ __forceinline__ f3 scattered_cell(f3 g, float half_scatter, uint32_t& hash) {
+    // Lattice coordinates and multipliers fit 24 signed bits, so the full-rate 24-bit multiply returns
+    // the same low 32 bits as the wrapping int multiply of the reference, and h * 31 = (h << 5) - h.
+    // Both are spelled in asm because the compiler folds the C forms back into quarter-rate v_mul_lo_u32.
+    uint32_t h = mul24_lo(static_cast<int>(g.x), 885889) + mul24_lo(static_cast<int>(g.y), 745273) + mul24_lo(static_cast<int>(g.z), 1220689);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        h |= (h & 0x0f0f0f0fu) << 4;
+        h = shl5(h) - h;
+    }
+    hash = h;
+    const float mx = fmaf(static_cast<float>(h & 0x3ffu), 1.0f / 512.0f, -1.0f);
+    const float my = fmaf(static_cast<float>((h >> 10) & 0x3ffu), 1.0f / 512.0f, -1.0f);
+    const float mz = fmaf(static_cast<float>((h >> 20) & 0x3ffu), 1.0f / 512.0f, -1.0f);
+    return mk3(fmaf(half_scatter, mx, g.x), fmaf(half_scatter, my, g.y), fmaf(half_scatter, mz, g.z));
+}
+
+// Projects a lattice point onto the sphere of radius `scale` about `off` and reports whether it lies
+// within sqrt(0.1) of that sphere (the `(point_on_sphere - point).normSquared() < 0.1f` tests).
+__device__ __forceinline__ bool project_cell(f3 point, f3 off, float scale, f3& on_sphere) {
+    const f3 v = point - off;
+    const float k = fast_rsq(fnorm2(v)) * scale;
+    on_sphere = mk3(fmaf(v.x, k, off.x), fmaf(v.y, k, off.y), fmaf(v.z, k, off.z));
+    return fnorm2(on_sphere - point) < 0.1f;
+}
+
+// ---- shared per-term formulas -------------------------------------------------------------------
+// Direction to the centre and the big-crater query point (:368-373).
+__device__ __forceinline__ void near_frame(f3 pos, f3 off, f3& u, f3& query) {
+    const float il = fast_rsq(fnorm2(pos));
+    u = mk3(-pos.x * il, -pos.y * il, -pos.z * il);
+    query = mk3(fmaf(u.x, 2.0f, off.x), fmaf(u.y, 2.0f, off.y), fmaf(u.z, 2.0f, off.z));
+}
+
+// The big craters of a ball do not depend on the query: a lattice cell passes the shell test or not,
+// and its point on the sphere, size, depth parameter and age follow from its hash alone.  They are
+// tabulated once per primitive (about 32 cells pass for any offset), three float4 per crater in lattice
+// order: {cell.xyz, size}, {on_sphere.xyz, t}, {age, 1 / (5 size), passes, -}.
+__global__ void __launch_bounds__(256) k_crater_cells(float ox, float oy, float oz, int bx, int by, int bz, int n, float4* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * n * n) return;
+    const int ix = i / (n * n), iy = (i / n) % n, iz = i % n;
+    const f3 off = mk3(ox, oy, oz);
+    const f3 g = mk3(static_cast<float>(bx + ix), static_cast<float>(by + iy), static_cast<float>(bz + iz));
+    uint32_t hash;
+    f3 on;
+    const f3 point = scattered_cell(g, 0.3f, hash);
+    const bool pass = project_cell(point, off, 2.0f, on);
+    const float t = static_cast<float>(hash & 0xffffu) * (1.0f / 65535.0f);
+    const float size = fmaf(0.4f * t, t, 0.05f);
+    out[3 * i] = make_float4(g.x, g.y, g.z, size);
+    out[3 * i + 1] = make_float4(on.x, on.y, on.z, t);
+    out[3 * i + 2] = make_float4(__uint_as_float(hash >> 16), fast_rcp(size * 5.0f), pass ? 1.0f : 0.0f, 0.0f);
+}
+
+// Is crater r0 one of the 4^3 cells about the query?  fl = floor(query) + 0.5; cell - floor(query) must be -1, 0, 1 or 2.
+__device__ __forceinline__ bool crater_in_reach(float4 r0, f3 fl) {
+    return fabsf(r0.x - fl.x) < 2.0f && fabsf(r0.y - fl.y) < 2.0f && fabsf(r0.z - fl.z) < 2.0f;
+}
+
+// One big crater at one query point (:381-408).
+struct BigCrater {
+    float depth, lin, k1, k2;   // depth profile, linear falloff, the two fallout noise arguments are on + k qv
+    f3 qv;
+    bool outside;
+};
+__device__ __forceinline__ BigCrater big_crater(f3 query, float4 r0, float4 r1, float4 r2) {
+    BigCrater b;
+    const float size = r0.w, t = r1.w;
+    b.qv = query - mk3(r1.x, r1.y, r1.z);
+    const float dist2 = fnorm2(b.qv);
+    const float idist = fast_rsq(fmaxf(dist2, 1e-30f));
+    const float dist = dist2 * idist;
+    const float c20 = 20.0f * (dist - size);
+    const float th = fast_tanh(c20);
+    // tanh(c) for c <= 1e-3, else 0.9 t tanh(c) / (0.02 / c + c^2) = 0.9 t tanh(c) c / (0.02 + c^3)
+    const float rim = ((0.9f * t) * th) * (c20 * fast_rcp(fmaf(c20 * c20, c20, 0.02f)));
+    b.depth = c20 > 1e-3f ? rim : th;
+    b.outside = dist >= size;
+    b.lin = fmaxf(0.0f, fmaf(-dist, r2.y, 1.2f));
+    const float si = size * idist;
+    b.k1 = 3.0f * si;
+    b.k2 = 40.0f * si;
+    return b;
+}
+__device__ __forceinline__ int big_crater_fix(const BigCrater& b) { return to_fix(-0.02f * b.depth); }
+
+// pow(0, y) = 0 for the y in [1, 3] that occurs, so a crater whose linear falloff is zero deposits
+// exactly nothing and its two noise() calls are skipped (lin > 0 is part of `deposits`).
+__device__ __forceinline__ int fallout_fix(float n1, float n2, float lin, float depth) {
+    const float falloff = fast_exp2(fmaf(3.0f, n1, 2.0f) * fast_log2(lin));
+    return to_fix(((0.1f * falloff) * fmaf(0.4f, depth, 0.2f)) * n2);
+}
+
+// One cell of the small (scale 10, :412-437) or tiny (scale 60, :440-463) craters.
+struct MinorCell {
+    bool pass;
+    uint32_t age;
+    float th, size, c50;
+};
+__device__ __forceinline__ MinorCell minor_cell(f3 q2, f3 cell, f3 off, float scale, bool tiny) {
+    MinorCell m;
+    uint32_t h2;
+    f3 on2;
+    const f3 pt2 = scattered_cell(cell, 0.5f, h2);
+    m.pass = project_cell(pt2, off, scale, on2);
+    const float t2 = static_cast<float>(h2 & 0xffffu) * (1.0f / 65535.0f);
+    m.age = h2 >> 16;
+    const float d2 = __builtin_amdgcn_sqrtf(fnorm2(q2 - on2));
+    m.size = tiny ? fmaf(0.35f, t2, 0.02f) : fmaf(0.35f * t2, t2, 0.05f);
+    m.c50 = 50.0f * (d2 - m.size);
+    m.th = fast_tanh(m.c50);
+    return m;
+}
+__device__ __forceinline__ float small_term(const MinorCell& m) { return -0.005f * m.th; }
+__device__ __forceinline__ float tiny_term(const MinorCell& m) { return (-0.004f * m.size) * fmaf(0.5f, m.th, -0.5f); }
+
+__device__ __forceinline__ float near_total(float s, int big_fix, float crater_small, float tiny, int fallout, float nf1, float nf2) {
+    const float crater = fmaxf(from_fix(big_fix), crater_small);
+    return ((((s + crater) + tiny) + from_fix(fallout)) + 0.01f * nf1) + 0.4f * nf2;
+}
+
+// What each lane contributes to the cooperative parts of an evaluation.
+struct CoopLane {
+    float si, sj, sk;     // lanes 0-7 / 8-15 of a row: cell of the 2^3 small / tiny-crater neighbourhood (0..1)
+    float A[9], b[3], k;  // noise octave (lane & 7): q = A p + b is the point the octave samples, k its weight
+};
+__device__ __forceinline__ CoopLane make_coop_lane(const float* noise_oct, uint32_t lane) {
+    CoopLane c;
+    c.si = static_cast<float>((lane >> 2) & 1u);
+    c.sj = static_cast<float>((lane >> 1) & 1u);
+    c.sk = static_cast<float>(lane & 1u);
+    const float* o = noise_oct + 13 * (lane & 7u);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.A[i] = o[i];
+    c.b[0] = o[9];
+    c.b[1] = o[10];
+    c.b[2] = o[11];
+    c.k = o[12];
+    return c;
+}
+
+// noise() :56-70 for 8 points at once: lane l evaluates octave l & 7 of the point its group of 8 lanes
+// holds (octave i samples A_i p + b_i with the composed affine held per lane), and a DPP sum over the 8
+// lanes returns the call's value in every lane of the group.
+__device__ __forceinline__ float noise_octaves(const CoopLane& cl, float x, float y, float z) {
+    const float qx = fmaf(cl.A[0], x, fmaf(cl.A[1], y, fmaf(cl.A[2], z, cl.b[0])));
+    const float qy = fmaf(cl.A[3], x, fmaf(cl.A[4], y, fmaf(cl.A[5], z, cl.b[1])));
+    const float qz = fmaf(cl.A[6], x, fmaf(cl.A[7], y, fmaf(cl.A[8], z, cl.b[2])));
+    // triangle(v) = -1 + 4 |v - 0.25 - floor(v + 0.25)| = 4 |fract(v + 0.25) - 0.5| - 1  (:26-28)
+    const float a = (fabsf(__builtin_amdgcn_fractf(qx + 0.25f) - 0.5f) + fabsf(__builtin_amdgcn_fractf(qy + 0.25f) - 0.5f)) +
+                    fabsf(__builtin_amdgcn_fractf(qz + 0.25f) - 0.5f);
+    float v = cl.k * a;
+    v += dpp_f<kQuadXor1>(0.0f, v);
+    v += dpp_f<kQuadXor2>(0.0f, v);
+    v += dpp_f<kRowHalfMirror>(0.0f, v);
+    // noise = sum_i k_i (4 a_i - 3) with sum_i k_i = 0.02 (1 - 0.9^8) / 0.1
+    return fmaf(4.0f, v, -3.0f * 0.11390656f);
+}
+
+// =============================================================================================
+// coop_near: G points (G = 1 or 4) whose sphere distances s = |pos| - 0.5 are already known to be
+// <= 0.1 (the far field returns s itself), evaluated by ONE WAVE: off, pos and s are wave-uniform and
+// every lane must be active.
+//
+//   * lane l holds crater l of the ball's table (r0..r2; lanes past the table hold a cell out of
+//     anyone's reach), one pass per point;
+//   * noise() calls -- two per big crater that deposits fallout, two for the final terms -- run as
+//     (point, octave) tasks, 8 calls per round; the calls of all G points share the rounds;
+//   * the 8 small-crater and 8 tiny-crater cells of point g run on the 16 lanes of DPP row g; the
+//     order dependence of the small craters through min_age is an exclusive prefix minimum.
+//
+// An evaluation costs a few hundred wave instructions with no data-dependent loop except the noise
+// rounds, so the 256-step worst case of a march is a fraction of a millisecond.
+// =============================================================================================
+constexpr int kCoopGroup = 4;                                    // points one wave evaluates together
+constexpr int kCoopPts = 2 * 64 * kCoopGroup + 2 * kCoopGroup;   // fallout points + final points (a multiple of 8)
+constexpr int kCoopLdsFloats = 4 * kCoopPts;                     // x, y, z, value
+
+template <int G>
+__device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, float4 r0, float4 r1, float4 r2, const f3 (&off)[G], const f3 (&pos)[G],
+                                          const float (&s)[G], uint32_t lane, float (&out)[G], uint32_t (&noise_calls)[G]) {
+    static_assert(G == 1 || G == kCoopGroup, "one point or a full group");
+    float* px = lds;
+    float* py = lds + kCoopPts;
+    float* pz = lds + 2 * kCoopPts;
+    float* pv = lds + 3 * kCoopPts;
+    f3 u[G];
+    float depth[G], lin[G];
+    int big_fix[G];
+    uint32_t rank[G], min_age0[G];
+    bool deposits[G];
+    uint32_t n_fall = 0;   // fallout points staged so far
+
+    // ---- big craters :375-409: one crater per lane, one pass per point -----------------------
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        f3 query;
+        near_frame(pos[g], off[g], u[g], query);
+        const f3 fl = mk3(floorf(query.x) + 0.5f, floorf(query.y) + 0.5f, floorf(query.z) + 0.5f);
+        const bool in = crater_in_reach(r0, fl);
+        const BigCrater b = big_crater(query, r0, r1, r2);
+        depth[g] = b.depth;
+        lin[g] = b.lin;
+        deposits[g] = in && b.outside && b.lin > 0.0f;
+        big_fix[g] = wave_sum_i(in ? big_crater_fix(b) : 0);
+        // ages are compared as their 16-bit integers (age = bits / 65535); 0xffff is the initial 1.0
+        min_age0[g] = wave_min_u((in && !b.outside) ? __float_as_uint(r2.x) : 0xffffu);
+        // stage this point's fallout noise() arguments
+        const unsigned long long dmask = __ballot(deposits[g]);
+        rank[g] = n_fall + 2u * lanes_below(dmask);
+        const uint32_t n_dep = __popcll(dmask);
+        n_fall += 2u * n_dep;
+        if (deposits[g]) {
+            px[rank[g]] = fmaf(b.k1, b.qv.x, r1.x);
+            py[rank[g]] = fmaf(b.k1, b.qv.y, r1.y);
+            pz[rank[g]] = fmaf(b.k1, b.qv.z, r1.z);
+            px[rank[g] + 1] = fmaf(b.k2, b.qv.x, r1.x);
+            py[rank[g] + 1] = fmaf(b.k2, b.qv.y, r1.y);
+            pz[rank[g] + 1] = fmaf(b.k2, b.qv.z, r1.z);
+        }
+        noise_calls[g] = 2u * n_dep + 2u;
+    }
+    // the two final noise() arguments of every point follow the fallout points
+    const uint32_t n_pts = n_fall + 2u * G;
+    if (lane < 2u * G) {
+        f3 q = pos[0] + off[0];
+#pragma unroll
+        for (int g = 1; g < G; ++g)
+            if ((lane >> 1) == static_cast<uint32_t>(g)) q = pos[g] + off[g];
+        const float f = (lane & 1u) ? 1.5f : 20.0f;
+        px[n_fall + lane] = q.x * f;
+        py[n_fall + lane] = q.y * f;
+        pz[n_fall + lane] = q.z * f;
+    }
+    wave_lds_fence();
+
+    // ---- noise() as (point, octave) tasks: 8 points per round ---------------------------------
+    for (uint32_t first = 0; first < n_pts; first += 8u) {
+        const uint32_t slot = first + (lane >> 3);
+        const float v = noise_octaves(cl, px[slot], py[slot], pz[slot]);   // slots past n_pts hold stale but finite data
+        if ((lane & 7u) == 0u) pv[slot] = v;
+    }
+    wave_lds_fence();
+
+    // ---- small craters on lanes 0-7 and tiny craters on lanes 8-15 of row g ---------------------
+    const uint32_t row = lane >> 4;
+    f3 ur = u[0], offr = off[0];
+    uint32_t min_age_r = min_age0[0];
+#pragma unroll
+    for (int g = 1; g < G; ++g)
+        if (row == static_cast<uint32_t>(g)) {
+            ur = u[g];
+            offr = off[g];
+            min_age_r = min_age0[g];
+        }
+    const bool in_use = row < static_cast<uint32_t>(G);
+    const bool tiny_lane = (lane & 8u) != 0u;
+    const float scale = tiny_lane ? 60.0f : 10.0f;
+    const f3 q2 = mk3(fmaf(ur.x, scale, offr.x), fmaf(ur.y, scale, offr.y), fmaf(ur.z, scale, offr.z));
+    const MinorCell mc = minor_cell(q2, mk3(floorf(q2.x) + cl.si, floorf(q2.y) + cl.sj, floorf(q2.z) + cl.sk), offr, scale, tiny_lane);
+    // A small-crater cell takes effect iff it passes the shell and rim tests and its age does not exceed
+    // the running minimum, which only cells that took effect lower: the running minimum before cell k is
+    // min(min_age0, ages of the earlier candidates), an exclusive prefix minimum over lanes 0-7 of the row.
+    const bool cand = in_use && !tiny_lane && mc.pass && mc.c50 < 0.0f && mc.age <= min_age_r;
+    const uint32_t xa = cand ? mc.age : 0xffffffffu;
+    uint32_t incl = xa;
+    incl = min(incl, dpp_u<kRowShr1>(0xffffffffu, incl));
+    incl = min(incl, dpp_u<kRowShr2>(0xffffffffu, incl));
+    incl = min(incl, dpp_u<kRowShr4>(0xffffffffu, incl));
+    const uint32_t excl = dpp_u<kRowShr1>(0xffffffffu, incl);
+    const bool takes = cand && mc.age <= excl;
+    const float crater_small_r = row_max(takes ? small_term(mc) : -3.402823466e38f);
+    const uint32_t min_age1 = min(min_age_r, row_min_u(xa));
+    const bool tiny_ok = in_use && tiny_lane && mc.pass && mc.age <= min_age1;
+    const float tiny_r = row_max(tiny_ok ? tiny_term(mc) : 0.0f);
+
+    // ---- fallout and the final sum per point -----------------------------------------------
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        int f = 0;
+        if (deposits[g]) f = fallout_fix(pv[rank[g]], pv[rank[g] + 1], lin[g], depth[g]);
+        const int fallout = wave_sum_i(f);
+        const float nf1 = pv[n_fall + 2 * g], nf2 = pv[n_fall + 2 * g + 1];
+        out[g] = near_total(s[g], big_fix[g], bcast_lane(crater_small_r, 16 * g), bcast_lane(tiny_r, 16 * g), fallout, nf1, nf2);
+    }
+    wave_lds_fence();
+}
+
+// =============================================================================================
+// lane_near: one point per lane.  A wave-uniform loop walks the ball's crater table (records in scalar
+// registers), the small and tiny craters go cell by cell, and only noise() stays cooperative: every
+// lane stages the arguments of its calls in a ring in LDS, and rounds of 8 calls x 8 octaves drain the
+// ring whenever half of it is full, writing each value to the LDS slot its owner named.
+// =============================================================================================
+constexpr int kRing = 256;          // staged noise() arguments; one crater step adds at most 128
+constexpr int kLaneDeposits = 8;    // fallout deposits one lane can hold; a point with more is left to the caller
+constexpr int kLaneLdsFloats = 4 * kRing + 4 * 64 * kLaneDeposits + 2 * 64 + 8;
+constexpr int kNearLdsFloats = kLaneLdsFloats > kCoopLdsFloats ? kLaneLdsFloats : kCoopLdsFloats;   // per wave, either evaluator
+
+__device__ __forceinline__ void noise_ring_rounds(const CoopLane& cl, float* lds, uint32_t lane, uint32_t& done, uint32_t staged, bool flush_all) {
+    wave_lds_fence();
+    const float* rx = lds;
+    const float* ry = lds + kRing;
+    const float* rz = lds + 2 * kRing;
+    const uint32_t* rt = reinterpret_cast<const uint32_t*>(lds + 3 * kRing);
+    while (flush_all ? done < staged : done + 8u <= staged) {
+        const uint32_t call = done + (lane >> 3);
+        const uint32_t slot = call & (kRing - 1);
+        const uint32_t target = rt[slot];
+        const float v = noise_octaves(cl, rx[slot], ry[slot], rz[slot]);
+        if ((lane & 7u) == 0u && call < staged) lds[target] = v;
+        done += 8u;
+    }
+    if (done > staged) done = staged;
+    wave_lds_fence();
+}
+
+// Evaluates the near field at `pos` for every lane with `active` set; all 64 lanes must call and the
+// crater table (`count` <= 64 records) is the same for all of them.  Returns false for a lane whose
+// point has more fallout deposits than a lane can hold; its `out` is then not written.
+__device__ __forceinline__ bool lane_near(const float4* __restrict__ craters, uint32_t count, const CoopLane& cl, float* lds, bool active, f3 pos,
+                                          f3 off, float s, uint32_t lane, float& out, uint32_t& noise_calls) {
+    float* rx = lds;
+    float* ry = lds + kRing;
+    float* rz = lds + 2 * kRing;
+    uint32_t* rt = reinterpret_cast<uint32_t*>(lds + 3 * kRing);
+    constexpr uint32_t kCol = 4 * kRing;                            // float4 {n1, n2, lin, depth} of deposit j of lane l at kCol + 4 (64 j + l)
+    constexpr uint32_t kFin = kCol + 4 * 64 * kLaneDeposits;        // the two final noise values of lane l at kFin + 2 l
+    f3 u, query;
+    near_frame(pos, off, u, query);
+    const f3 fl = mk3(floorf(query.x) + 0.5f, floorf(query.y) + 0.5f, floorf(query.z) + 0.5f);
+    // the two final noise() calls of every active lane open the ring
+    const unsigned long long am = __ballot(active);
+    uint32_t staged = 2u * static_cast<uint32_t>(__popcll(am)), done = 0;
+    if (active) {
+        const uint32_t r = 2u * lanes_below(am);
+        const f3 q = pos + off;
+        rx[r] = q.x * 20.0f;
+        ry[r] = q.y * 20.0f;
+        rz[r] = q.z * 20.0f;
+        rt[r] = kFin + 2u * lane;
+        rx[r + 1] = q.x * 1.5f;
+        ry[r + 1] = q.y * 1.5f;
+        rz[r + 1] = q.z * 1.5f;
+        rt[r + 1] = kFin + 2u * lane + 1u;
+    }
+
+    // ---- big craters from the table ----------------------------------------------------------
+    int big_fix = 0;
+    uint32_t min_age = 0xffffu, n_dep = 0;
+    bool overflow = false;
+    for (uint32_t c = 0; c < count; ++c) {
+        const float4 r0 = craters[3 * c], r1 = craters[3 * c + 1], r2 = craters[3 * c + 2];
+        const bool in = active && crater_in_reach(r0, fl);
+        bool dep = false;
+        BigCrater b;
+        if (in) {
+            b = big_crater(query, r0, r1, r2);
+            big_fix += big_crater_fix(b);
+            if (!b.outside) min_age = min(min_age, __float_as_uint(r2.x));
+            dep = b.outside && b.lin > 0.0f;
+            if (dep && n_dep >= static_cast<uint32_t>(kLaneDeposits)) {
+                overflow = true;
+                dep = false;
+            }
+        }
+        const unsigned long long dm = __ballot(dep);
+        if (dm) {
+            if (dep) {
+                const uint32_t call = staged + 2u * lanes_below(dm);
+                const uint32_t s0 = call & (kRing - 1), s1 = (call + 1u) & (kRing - 1);
+                const uint32_t col = kCol + 4u * (64u * n_dep + lane);
+                rx[s0] = fmaf(b.k1, b.qv.x, r1.x);
+                ry[s0] = fmaf(b.k1, b.qv.y, r1.y);
+                rz[s0] = fmaf(b.k1, b.qv.z, r1.z);
+                rt[s0] = col;
+                rx[s1] = fmaf(b.k2, b.qv.x, r1.x);
+                ry[s1] = fmaf(b.k2, b.qv.y, r1.y);
+                rz[s1] = fmaf(b.k2, b.qv.z, r1.z);
+                rt[s1] = col + 1u;
+                lds[col + 2] = b.lin;
+                lds[col + 3] = b.depth;
+                ++n_dep;
+            }
+            staged += 2u * static_cast<uint32_t>(__popcll(dm));
+            if (staged - done >= 128u) noise_ring_rounds(cl, lds, lane, done, staged, false);
+        }
+    }
+
+    // ---- small and tiny craters, cell by cell in the reference's order --------------------------
+    float crater_small = -3.402823466e38f, tiny = 0.0f;
+    if (active) {
+#pragma unroll 1
+        for (int pass_no = 0; pass_no < 2; ++pass_no) {
+            const bool is_tiny = pass_no != 0;
+            const float scale = is_tiny ? 60.0f : 10.0f;
+            const f3 q2 = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
+            const f3 f2 = mk3(floorf(q2.x), floorf(q2.y), floorf(q2.z));
+#pragma unroll 1
+            for (int cell = 0; cell < 8; ++cell) {
+                const f3 g = mk3(f2.x + static_cast<float>(cell >> 2), f2.y + static_cast<float>((cell >> 1) & 1), f2.z + static_cast<float>(cell & 1));
+                const MinorCell mc = minor_cell(q2, g, off, scale, is_tiny);
+                if (!is_tiny) {
+                    if (mc.pass && mc.c50 < 0.0f && mc.age <= min_age) {
+                        crater_small = fmaxf(crater_small, small_term(mc));
+                        min_age = mc.age;
+                    }
+                } else if (mc.pass && mc.age <= min_age) {
+                    tiny = fmaxf(tiny, tiny_term(mc));
+                }
+            }
+        }
+    }
+
+    // ---- remaining noise() calls, then fallout and the final sum ----------------------------------
+    noise_ring_rounds(cl, lds, lane, done, staged, true);
+    if (active && !overflow) {
+        int fallout = 0;
+        for (uint32_t j = 0; j < n_dep; ++j) {
+            const float4 e = *reinterpret_cast<const float4*>(lds + kCol + 4u * (64u * j + lane));
+            fallout += fallout_fix(e.x, e.y, e.z, e.w);
+        }
+        const float nf1 = lds[kFin + 2u * lane], nf2 = lds[kFin + 2u * lane + 1u];
+        out = near_total(s, big_fix, crater_small, tiny, fallout, nf1, nf2);
+        noise_calls = 2u * n_dep + 2u;
+    }
+    wave_lds_fence();
+    return !overflow;
+}
+
+// =============================================================================================
+// wave_near: near-field values for every lane with `wants` set (all 64 lanes must call).  Lanes are
+// served primitive by primitive; per primitive, one point per lane when at least `lane_threshold`
+// lanes wait, otherwise (and for the rare point lane_near leaves over) the whole wave works on groups
+// of four points, then on single points.
+// =============================================================================================
+__device__ __forceinline__ void wave_near(const float* crater_table, const CoopLane& cl, float* lds, uint32_t lane, uint32_t lane_threshold, bool wants,
+                                          f3 p, f3 off, float s, uint32_t crater_base, uint32_t crater_count, float& value, uint32_t& n_evals,
+                                          uint32_t& n_noise) {
+    unsigned long long todo = __ballot(wants);
+    while (todo) {
+        const int first = __ffsll(static_cast<long long>(todo)) - 1;
+        const uint32_t base = bcast_lane_u(crater_base, first), count = bcast_lane_u(crater_count, first);
+        const bool mine = wants && crater_base == base;
+        unsigned long long need = __ballot(mine);
+        todo &= ~need;
+        const float4* table = reinterpret_cast<const float4*>(crater_table) + 3u * base;
+        if (static_cast<uint32_t>(__popcll(need)) >= lane_threshold) {
+            float v = 0.0f;
+            uint32_t calls = 0;
+            const bool ok = lane_near(table, count, cl, lds, mine, p, off, s, lane, v, calls);
+            if (mine && ok) {
+                value = v;
+                n_noise += calls;
+                ++n_evals;
+            }
+            need &= ~__ballot(mine && ok);
+        }
+        if (!need) continue;
+        float4 r0 = make_float4(1e30f, 1e30f, 1e30f, 1.0f), r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r2 = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
+        if (lane < count) {
+            r0 = table[3u * lane];
+            r1 = table[3u * lane + 1u];
+            r2 = table[3u * lane + 2u];
+        }
+        while (__popcll(need) >= kCoopGroup) {
+            int src[kCoopGroup];
+            f3 P[kCoopGroup], O[kCoopGroup];
+            float S[kCoopGroup], val[kCoopGroup];
+            uint32_t calls[kCoopGroup];
+#pragma unroll
+            for (int g = 0; g < kCoopGroup; ++g) {
+                src[g] = __ffsll(static_cast<long long>(need)) - 1;
+                need &= need - 1ull;
+                P[g] = mk3(bcast_lane(p.x, src[g]), bcast_lane(p.y, src[g]), bcast_lane(p.z, src[g]));
+                O[g] = mk3(bcast_lane(off.x, src[g]), bcast_lane(off.y, src[g]), bcast_lane(off.z, src[g]));
+                S[g] = bcast_lane(s, src[g]);
+            }
+            coop_near<kCoopGroup>(cl, lds, r0, r1, r2, O, P, S, lane, val, calls);
+#pragma unroll
+            for (int g = 0; g < kCoopGroup; ++g)
+                if (lane == static_cast<uint32_t>(src[g])) {
+                    value = val[g];
+                    n_noise += calls[g];
+                    ++n_evals;
+                }
+        }
+        while (need) {
+            const int src = __ffsll(static_cast<long long>(need)) - 1;
+            need &= need - 1ull;
+            const f3 P[1] = {mk3(bcast_lane(p.x, src), bcast_lane(p.y, src), bcast_lane(p.z, src))};
+            const f3 O[1] = {mk3(bcast_lane(off.x, src), bcast_lane(off.y, src), bcast_lane(off.z, src))};
+            const float S[1] = {bcast_lane(s, src)};
+            float val[1];
+            uint32_t calls[1];
+            coop_near<1>(cl, lds, r0, r1, r2, O, P, S, lane, val, calls);
+            if (lane == static_cast<uint32_t>(src)) {
+                value = val[0];
+                n_noise += calls[0];
+                ++n_evals;
+            }
+        }
+    }
+}

@@ -29,6 +29,7 @@ struct BatchParams {
     uint32_t width, height;
     uint32_t first_sample;  // global sample index of sample 0 of this batch
     uint32_t flags;
+    uint32_t lane_threshold;   // SDF near field: waiting lanes from which a wave evaluates one point per lane
     uint64_t seed;
 };
 

@@ -476,526 +476,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
     if (n_sdf_rays) atomicAdd(&pb.totals->sdf_rays, static_cast<unsigned long long>(n_sdf_rays));
 }
 
-// =============================================================================================
-// fast part: crater-ball SDF (PathTracerDemo.cpp:26-116, 361-466)
-// =============================================================================================
-#pragma clang fp contract(fast)
-
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
-// tanh(c) = 1 - 2 / (exp(2c) + 1); absolute error ~1e-7, which is what the SDF terms it feeds need
-__device__ __forceinline__ float fast_tanh(float c) {
-    const float e = fast_exp2(c * 2.885390081777927f);   // 2 / ln 2
-    return 1.0f - 2.0f * fast_rcp(e + 1.0f);
-}
-
-// ---- wave-wide reductions on the DPP crossbar (every lane must be active) --------------------
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp_f(float identity, float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ uint32_t dpp_u(uint32_t identity, uint32_t v) {
-    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(identity), static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
-}
-constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kRowHalfMirror = 0x141, kRowMirror = 0x140, kRowBcast15 = 0x142, kRowBcast31 = 0x143;
-constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114;
-
-__device__ __forceinline__ float wave_sum(float v) {
-    v += dpp_f<kQuadXor1>(0.0f, v);
-    v += dpp_f<kQuadXor2>(0.0f, v);
-    v += dpp_f<kRowHalfMirror>(0.0f, v);
-    v += dpp_f<kRowMirror>(0.0f, v);
-    v += dpp_f<kRowBcast15, 0xa>(0.0f, v);
-    v += dpp_f<kRowBcast31, 0xc>(0.0f, v);
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ __forceinline__ float wave_max(float v) {
-    const float ninf = -3.402823466e38f;
-    v = fmaxf(v, dpp_f<kQuadXor1>(ninf, v));
-    v = fmaxf(v, dpp_f<kQuadXor2>(ninf, v));
-    v = fmaxf(v, dpp_f<kRowHalfMirror>(ninf, v));
-    v = fmaxf(v, dpp_f<kRowMirror>(ninf, v));
-    v = fmaxf(v, dpp_f<kRowBcast15, 0xa>(ninf, v));
-    v = fmaxf(v, dpp_f<kRowBcast31, 0xc>(ninf, v));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ __forceinline__ uint32_t wave_min_u(uint32_t v) {
-    v = min(v, dpp_u<kQuadXor1>(0xffffffffu, v));
-    v = min(v, dpp_u<kQuadXor2>(0xffffffffu, v));
-    v = min(v, dpp_u<kRowHalfMirror>(0xffffffffu, v));
-    v = min(v, dpp_u<kRowMirror>(0xffffffffu, v));
-    v = min(v, dpp_u<kRowBcast15, 0xa>(0xffffffffu, v));
-    v = min(v, dpp_u<kRowBcast31, 0xc>(0xffffffffu, v));
-    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
-}
-__device__ __forceinline__ float bcast_lane(float v, int lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-__device__ __forceinline__ uint32_t mul24_lo(int a, int k) {
-    int r;
-    asm("v_mul_i32_i24_e32 %0, %1, %2" : "=v"(r) : "s"(k), "v"(a));
-    return static_cast<uint32_t>(r);
-}
-__device__ __forceinline__ uint32_t shl5(uint32_t h) {
-    uint32_t r;
-    asm("v_lshlrev_b32_e32 %0, 5, %1" : "=v"(r) : "v"(h));
-    return r;
-}
-
-// One cell of for_each_nearby_scattered_point :79-116: hashed, jittered lattice point.  The reference
-// forms the jitter through double; fmaf(scatter/2, m, g) rounds the same exact value once.
-__device__ __forceinline__ f3 scattered_cell(f3 g, float half_scatter, uint32_t& hash) {
-    // Lattice coordinates and multipliers fit 24 signed bits, so the full-rate 24-bit multiply returns
-    // the same low 32 bits as the wrapping int multiply of the reference, and h * 31 = (h << 5) - h.
-    // Both are spelled in asm because the compiler folds the C forms back into quarter-rate v_mul_lo_u32.
-    uint32_t h = mul24_lo(static_cast<int>(g.x), 885889) + mul24_lo(static_cast<int>(g.y), 745273) + mul24_lo(static_cast<int>(g.z), 1220689);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        h |= (h & 0x0f0f0f0fu) << 4;
-        h = shl5(h) - h;
-    }
-    hash = h;
-    const float mx = static_cast<float>(h & 0x3ffu) * (1.0f / 512.0f) - 1.0f;
-    const float my = static_cast<float>((h >> 10) & 0x3ffu) * (1.0f / 512.0f) - 1.0f;
-    const float mz = static_cast<float>((h >> 20) & 0x3ffu) * (1.0f / 512.0f) - 1.0f;
-    return mk3(fmaf(half_scatter, mx, g.x), fmaf(half_scatter, my, g.y), fmaf(half_scatter, mz, g.z));
-}
-
-// Projects a lattice point onto the sphere of radius `scale` about `off` and reports whether it lies
-// within sqrt(0.1) of that sphere (the `(point_on_sphere - point).normSquared() < 0.1f` tests).
-__device__ __forceinline__ bool project_cell(f3 point, f3 off, float scale, f3& on_sphere) {
-    const f3 v = point - off;
-    const float il = fast_rsq(norm_sq(v));
-    on_sphere = mk3(fmaf(v.x, il * scale, off.x), fmaf(v.y, il * scale, off.y), fmaf(v.z, il * scale, off.z));
-    return norm_sq(on_sphere - point) < 0.1f;
-}
-
-// What each lane contributes to a wave-cooperative SDF evaluation.
-struct CoopLane {
-    float bi, bj, bk;     // this lane's cell of the 4^3 big-crater neighbourhood (-1..2 per axis)
-    float si, sj, sk;     // lanes 0-7 / 8-15: cell of the 2^3 small / tiny-crater neighbourhood (0..1)
-    float A[9], b[3], k;  // noise octave (lane & 7): q = A p + b is the point the octave samples, k its weight
-};
-constexpr int kCoopGroup = 4;                                    // points one wave evaluates together
-constexpr int kCoopPts = 2 * 64 * kCoopGroup + 2 * kCoopGroup;   // fallout points + final points (a multiple of 8)
-constexpr int kCoopLdsFloats = 4 * kCoopPts;                     // x, y, z, value
-
-__device__ __forceinline__ CoopLane make_coop_lane(const float* noise_oct, uint32_t lane) {
-    CoopLane c;
-    c.bi = static_cast<float>(static_cast<int>(lane >> 4) - 1);
-    c.bj = static_cast<float>(static_cast<int>((lane >> 2) & 3u) - 1);
-    c.bk = static_cast<float>(static_cast<int>(lane & 3u) - 1);
-    c.si = static_cast<float>((lane >> 2) & 1u);
-    c.sj = static_cast<float>((lane >> 1) & 1u);
-    c.sk = static_cast<float>(lane & 1u);
-    const float* o = noise_oct + 13 * (lane & 7u);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) c.A[i] = o[i];
-    c.b[0] = o[9];
-    c.b[1] = o[10];
-    c.b[2] = o[11];
-    c.k = o[12];
-    return c;
-}
-
-// row-wise (16 lanes) reductions: afterwards every lane of a row holds the row's result
-__device__ __forceinline__ float row_max(float v) {
-    const float ninf = -3.402823466e38f;
-    v = fmaxf(v, dpp_f<kQuadXor1>(ninf, v));
-    v = fmaxf(v, dpp_f<kQuadXor2>(ninf, v));
-    v = fmaxf(v, dpp_f<kRowHalfMirror>(ninf, v));
-    v = fmaxf(v, dpp_f<kRowMirror>(ninf, v));
-    return v;
-}
-__device__ __forceinline__ uint32_t row_min_u(uint32_t v) {
-    v = min(v, dpp_u<kQuadXor1>(0xffffffffu, v));
-    v = min(v, dpp_u<kQuadXor2>(0xffffffffu, v));
-    v = min(v, dpp_u<kRowHalfMirror>(0xffffffffu, v));
-    v = min(v, dpp_u<kRowMirror>(0xffffffffu, v));
-    return v;
-}
-
-// CraterBallObject::signedDistance :361-466 for G points (G = 1 or 4) whose sphere distances
-// s = |pos| - 0.5 are already known to be <= 0.1 (the far field returns s itself), evaluated by ONE
-// WAVE: off, pos and s are wave-uniform and every lane must be active.
-//
-//   * the 64 cells of a point's big-crater neighbourhood map to the 64 lanes (one pass per point);
-//   * noise() calls -- two per big-crater cell that deposits fallout, two for the final terms -- are
-//     cut into their 8 octaves and spread over the wave as (point, octave) tasks: octave i samples
-//     A_i p + b_i with the composed affine held per lane, so the octaves of a call run side by side
-//     instead of one after another, and a DPP sum over 8 lanes returns the call's value; the calls
-//     of all G points share the rounds;
-//   * the 8 small-crater and 8 tiny-crater cells of point g run on the 16 lanes of DPP row g; the
-//     order dependence of the small craters through min_age is an exclusive prefix minimum.
-//
-// An evaluation costs a few hundred wave instructions with no data-dependent loop except the noise
-// rounds, instead of ~13,000 lane instructions in a divergent loop, so the 256-step worst case of a
-// march is a fraction of a millisecond.  Sums are tree reductions: values differ from a sequential
-// evaluation by rounding only, and a point's value does not depend on G or on its companions.
-//
-// pow(0, y) = 0 for the y in [1, 3] that occurs, so a cell whose linear falloff is zero adds exactly
-// nothing to the fallout and its two noise() calls are skipped.
-template <int G>
-__device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, const f3 (&off)[G], const f3 (&pos)[G], const float (&s)[G],
-                                          uint32_t lane, float (&out)[G], uint32_t (&noise_calls)[G]) {
-    static_assert(G == 1 || G == kCoopGroup, "one point or a full group");
-    float* px = lds;
-    float* py = lds + kCoopPts;
-    float* pz = lds + 2 * kCoopPts;
-    float* pv = lds + 3 * kCoopPts;
-    f3 u[G];
-    float depth[G], lin[G], crater_big[G];
-    uint32_t rank[G], min_age0[G];
-    bool deposits[G];
-    uint32_t n_fall = 0;   // fallout points staged so far
-
-    // ---- big craters :375-409: one cell per lane, one pass per point -------------------------
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const float il = fast_rsq(norm_sq(pos[g]));
-        u[g] = mk3(-pos[g].x * il, -pos[g].y * il, -pos[g].z * il);
-        const f3 query = mk3(fmaf(u[g].x, 2.0f, off[g].x), fmaf(u[g].y, 2.0f, off[g].y), fmaf(u[g].z, 2.0f, off[g].z));
-        uint32_t hash;
-        f3 on;
-        const f3 point = scattered_cell(mk3(floorf(query.x) + cl.bi, floorf(query.y) + cl.bj, floorf(query.z) + cl.bk), 0.3f, hash);
-        const bool pass = project_cell(point, off[g], 2.0f, on);
-        const float t = static_cast<float>(hash & 0xffffu) * (1.0f / 65535.0f);
-        const float size = fmaf(0.4f * t, t, 0.05f);
-        const f3 qv = query - on;
-        const float dist2 = norm_sq(qv);
-        const float idist = fast_rsq(fmaxf(dist2, 1e-30f));
-        const float dist = dist2 * idist;
-        const float c20 = 20.0f * (dist - size);
-        const float th = fast_tanh(c20);
-        // tanh(c) for c <= 1e-3, else 0.9 t tanh(c) / (0.02 / c + c^2) = 0.9 t tanh(c) c / (0.02 + c^3)
-        const float rim = 0.9f * t * th * c20 * fast_rcp(fmaf(c20 * c20, c20, 0.02f));
-        depth[g] = c20 > 1e-3f ? rim : th;
-        const bool outside = dist >= size;
-        lin[g] = fmaxf(0.0f, 1.2f - dist * fast_rcp(size * 5.0f));
-        deposits[g] = pass && outside && lin[g] > 0.0f;
-        crater_big[g] = wave_sum(pass ? -0.02f * depth[g] : 0.0f);
-        // ages are compared as their 16-bit integers (age = bits / 65535); 0xffff is the initial 1.0
-        min_age0[g] = wave_min_u((pass && !outside) ? (hash >> 16) : 0xffffu);
-        // stage this point's fallout noise() arguments
-        const unsigned long long dmask = __ballot(deposits[g]);
-        const uint32_t n_dep = __popcll(dmask);
-        rank[g] = n_fall + 2u * __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(dmask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(dmask), 0u));
-        n_fall += 2u * n_dep;
-        if (deposits[g]) {
-            const float k1 = 3.0f * size * idist, k2 = 40.0f * size * idist;
-            px[rank[g]] = fmaf(k1, qv.x, on.x);
-            py[rank[g]] = fmaf(k1, qv.y, on.y);
-            pz[rank[g]] = fmaf(k1, qv.z, on.z);
-            px[rank[g] + 1] = fmaf(k2, qv.x, on.x);
-            py[rank[g] + 1] = fmaf(k2, qv.y, on.y);
-            pz[rank[g] + 1] = fmaf(k2, qv.z, on.z);
-        }
-        noise_calls[g] = 2u * n_dep + 2u;
-    }
-    // the two final noise() arguments of every point follow the fallout points
-    const uint32_t n_pts = n_fall + 2u * G;
-    if (lane < 2u * G) {
-        f3 q = pos[0] + off[0];
-#pragma unroll
-        for (int g = 1; g < G; ++g)
-            if ((lane >> 1) == static_cast<uint32_t>(g)) q = pos[g] + off[g];
-        const float f = (lane & 1u) ? 1.5f : 20.0f;
-        px[n_fall + lane] = q.x * f;
-        py[n_fall + lane] = q.y * f;
-        pz[n_fall + lane] = q.z * f;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- noise() :56-70 as (point, octave) tasks: 8 points per round ---------------------------
-    for (uint32_t first = 0; first < n_pts; first += 8u) {
-        const uint32_t slot = first + (lane >> 3);
-        const float x = px[slot], y = py[slot], z = pz[slot];   // slots past n_pts hold stale but finite data
-        const float qx = fmaf(cl.A[0], x, fmaf(cl.A[1], y, fmaf(cl.A[2], z, cl.b[0])));
-        const float qy = fmaf(cl.A[3], x, fmaf(cl.A[4], y, fmaf(cl.A[5], z, cl.b[1])));
-        const float qz = fmaf(cl.A[6], x, fmaf(cl.A[7], y, fmaf(cl.A[8], z, cl.b[2])));
-        // triangle(v) = -1 + 4 |v - 0.25 - floor(v + 0.25)| = 4 |fract(v + 0.25) - 0.5| - 1  (:26-28)
-        const float a = (fabsf(__builtin_amdgcn_fractf(qx + 0.25f) - 0.5f) + fabsf(__builtin_amdgcn_fractf(qy + 0.25f) - 0.5f)) +
-                        fabsf(__builtin_amdgcn_fractf(qz + 0.25f) - 0.5f);
-        float v = cl.k * a;
-        v += dpp_f<kQuadXor1>(0.0f, v);
-        v += dpp_f<kQuadXor2>(0.0f, v);
-        v += dpp_f<kRowHalfMirror>(0.0f, v);
-        // noise = sum_i k_i (4 a_i - 3) with sum_i k_i = 0.02 (1 - 0.9^8) / 0.1
-        if ((lane & 7u) == 0u) pv[slot] = fmaf(4.0f, v, -3.0f * 0.11390656f);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- small craters :412-437 on lanes 0-7 and tiny craters :440-463 on lanes 8-15 of row g ----
-    const uint32_t row = lane >> 4;
-    f3 ur = u[0], offr = off[0];
-    uint32_t min_age_r = min_age0[0];
-#pragma unroll
-    for (int g = 1; g < G; ++g)
-        if (row == static_cast<uint32_t>(g)) {
-            ur = u[g];
-            offr = off[g];
-            min_age_r = min_age0[g];
-        }
-    const bool in_use = row < static_cast<uint32_t>(G);
-    const bool is_small = in_use && (lane & 8u) == 0u, is_tiny = in_use && (lane & 8u) != 0u;
-    const float scale = (lane & 8u) == 0u ? 10.0f : 60.0f;
-    const f3 q2 = mk3(fmaf(ur.x, scale, offr.x), fmaf(ur.y, scale, offr.y), fmaf(ur.z, scale, offr.z));
-    uint32_t h2;
-    f3 on2;
-    const f3 pt2 = scattered_cell(mk3(floorf(q2.x) + cl.si, floorf(q2.y) + cl.sj, floorf(q2.z) + cl.sk), 0.5f, h2);
-    const bool pass2 = project_cell(pt2, offr, scale, on2);
-    const float t2 = static_cast<float>(h2 & 0xffffu) * (1.0f / 65535.0f);
-    const uint32_t age2 = h2 >> 16;
-    const float d2 = sqrtf(norm_sq(q2 - on2));
-    const float size2 = (lane & 8u) == 0u ? fmaf(0.35f * t2, t2, 0.05f) : fmaf(0.35f, t2, 0.02f);
-    const float c50 = 50.0f * (d2 - size2);
-    const float th = fast_tanh(c50);
-    // A small-crater cell takes effect iff it passes the shell and rim tests and its age does not exceed
-    // the running minimum, which only cells that took effect lower: the running minimum before cell k is
-    // min(min_age0, ages of the earlier candidates), an exclusive prefix minimum over lanes 0-7 of the row.
-    const bool cand = is_small && pass2 && c50 < 0.0f && age2 <= min_age_r;
-    const uint32_t xa = cand ? age2 : 0xffffffffu;
-    uint32_t incl = xa;
-    incl = min(incl, dpp_u<kRowShr1>(0xffffffffu, incl));
-    incl = min(incl, dpp_u<kRowShr2>(0xffffffffu, incl));
-    incl = min(incl, dpp_u<kRowShr4>(0xffffffffu, incl));
-    const uint32_t excl = dpp_u<kRowShr1>(0xffffffffu, incl);
-    const bool takes = cand && age2 <= excl;
-    const float crater_small_r = row_max(takes ? -0.005f * th : -3.402823466e38f);
-    const uint32_t min_age1 = min(min_age_r, row_min_u(xa));
-    const bool tiny_ok = is_tiny && pass2 && age2 <= min_age1;
-    const float tiny_r = row_max(tiny_ok ? -0.004f * size2 * (-0.5f + 0.5f * th) : 0.0f);
-
-    // ---- fallout and the final sum per point -----------------------------------------------
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        float fallout_c = 0.0f;
-        if (deposits[g]) {
-            const float n1 = pv[rank[g]], n2 = pv[rank[g] + 1];
-            const float falloff = fast_exp2((2.0f + 3.0f * n1) * fast_log2(lin[g]));
-            fallout_c = 0.1f * falloff * (0.2f + 0.4f * depth[g]) * n2;
-        }
-        const float fallout = wave_sum(fallout_c);
-        const float nf1 = pv[n_fall + 2 * g], nf2 = pv[n_fall + 2 * g + 1];
-        const float crater = fmaxf(crater_big[g], bcast_lane(crater_small_r, 16 * g));
-        out[g] = s[g] + crater + bcast_lane(tiny_r, 16 * g) + fallout + 0.01f * nf1 + 0.4f * nf2;
-    }
-}
-
-// =============================================================================================
-// The big craters of a ball do not depend on the query: a lattice cell passes the shell test or not,
-// and its point on the sphere, size, depth parameter and age follow from its hash alone.  They are
-// tabulated once per primitive (about 32 cells pass for any offset; three float4 per cell, lattice
-// order): {cell.xyz, size}, {on_sphere.xyz, t}, {age, 1 / (5 size), -, -}.
-// =============================================================================================
-__global__ void __launch_bounds__(256) k_crater_cells(float ox, float oy, float oz, int bx, int by, int bz, int n, float4* out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * n * n) return;
-    const int ix = i / (n * n), iy = (i / n) % n, iz = i % n;
-    const f3 off = mk3(ox, oy, oz);
-    const f3 g = mk3(static_cast<float>(bx + ix), static_cast<float>(by + iy), static_cast<float>(bz + iz));
-    uint32_t hash;
-    f3 on;
-    const f3 point = scattered_cell(g, 0.3f, hash);
-    const bool pass = project_cell(point, off, 2.0f, on);
-    const float t = static_cast<float>(hash & 0xffffu) * (1.0f / 65535.0f);
-    const float size = fmaf(0.4f * t, t, 0.05f);
-    out[3 * i] = make_float4(g.x, g.y, g.z, size);
-    out[3 * i + 1] = make_float4(on.x, on.y, on.z, t);
-    out[3 * i + 2] = make_float4(__uint_as_float(hash >> 16), fast_rcp(size * 5.0f), pass ? 1.0f : 0.0f, 0.0f);
-}
-
-// ---- lane-parallel near field: one point per lane -------------------------------------------------
-// When most lanes of a wave need a near-field value at once, the wave evaluates them side by side:
-// a wave-uniform loop over the primitive's crater table (records in scalar registers), the small and
-// tiny craters cell by cell, and only noise() stays cooperative -- every lane stages the arguments of
-// its calls in a ring in LDS, and rounds of 8 calls x 8 octaves drain the ring whenever half of it is
-// full, writing each value to the LDS slot its owner named.
-constexpr int kRing = 256;          // staged noise() arguments; one crater step adds at most 128
-constexpr int kLaneDeposits = 8;    // fallout deposits one lane can hold; a point with more is left to the caller
-constexpr int kLaneLdsFloats = 4 * kRing + 4 * 64 * kLaneDeposits + 2 * 64 + 8;
-constexpr int kNearLdsFloats = kLaneLdsFloats > kCoopLdsFloats ? kLaneLdsFloats : kCoopLdsFloats;   // per wave, either way of evaluating
-constexpr int kLaneThreshold = 24;   // lanes that must be waiting before the lane-parallel evaluation pays
-
-__device__ __forceinline__ void noise_ring_rounds(const CoopLane& cl, float* lds, uint32_t lane, uint32_t& done, uint32_t staged, bool flush_all) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const float* rx = lds;
-    const float* ry = lds + kRing;
-    const float* rz = lds + 2 * kRing;
-    const uint32_t* rt = reinterpret_cast<const uint32_t*>(lds + 3 * kRing);
-    while (flush_all ? done < staged : done + 8u <= staged) {
-        const uint32_t call = done + (lane >> 3);
-        const uint32_t slot = call & (kRing - 1);
-        const float x = rx[slot], y = ry[slot], z = rz[slot];
-        const uint32_t target = rt[slot];
-        const float qx = fmaf(cl.A[0], x, fmaf(cl.A[1], y, fmaf(cl.A[2], z, cl.b[0])));
-        const float qy = fmaf(cl.A[3], x, fmaf(cl.A[4], y, fmaf(cl.A[5], z, cl.b[1])));
-        const float qz = fmaf(cl.A[6], x, fmaf(cl.A[7], y, fmaf(cl.A[8], z, cl.b[2])));
-        const float a = (fabsf(__builtin_amdgcn_fractf(qx + 0.25f) - 0.5f) + fabsf(__builtin_amdgcn_fractf(qy + 0.25f) - 0.5f)) +
-                        fabsf(__builtin_amdgcn_fractf(qz + 0.25f) - 0.5f);
-        float v = cl.k * a;
-        v += dpp_f<kQuadXor1>(0.0f, v);
-        v += dpp_f<kQuadXor2>(0.0f, v);
-        v += dpp_f<kRowHalfMirror>(0.0f, v);
-        if ((lane & 7u) == 0u && call < staged) lds[target] = fmaf(4.0f, v, -3.0f * 0.11390656f);
-        done += 8u;
-    }
-    if (done > staged) done = staged;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// Evaluates the near field at `pos` for every lane with `active` set; all 64 lanes must call.  The
-// lanes' primitive (crater table, `count` records) is wave-uniform.  Returns false for a lane whose
-// point has more fallout deposits than a lane can hold; its `out` is then not written.
-__device__ __forceinline__ bool lane_near(const float4* __restrict__ craters, uint32_t count, const CoopLane& cl, float* lds, bool active, f3 pos,
-                                          f3 off, float s, uint32_t lane, float& out, uint32_t& noise_calls) {
-    float* rx = lds;
-    float* ry = lds + kRing;
-    float* rz = lds + 2 * kRing;
-    uint32_t* rt = reinterpret_cast<uint32_t*>(lds + 3 * kRing);
-    constexpr uint32_t kCol = 4 * kRing;                            // float4 {n1, n2, lin, depth} of deposit j of lane l at kCol + 4 (64 j + l)
-    constexpr uint32_t kFin = kCol + 4 * 64 * kLaneDeposits;        // the two final noise values of lane l at kFin + 2 l
-    const float il = fast_rsq(norm_sq(pos));
-    const f3 u = mk3(-pos.x * il, -pos.y * il, -pos.z * il);
-    const f3 query = mk3(fmaf(u.x, 2.0f, off.x), fmaf(u.y, 2.0f, off.y), fmaf(u.z, 2.0f, off.z));
-    const f3 fl = mk3(floorf(query.x) + 0.5f, floorf(query.y) + 0.5f, floorf(query.z) + 0.5f);
-    // the two final noise() calls of every active lane open the ring
-    const unsigned long long am = __ballot(active);
-    uint32_t staged = 2u * static_cast<uint32_t>(__popcll(am)), done = 0;
-    if (active) {
-        const uint32_t r = 2u * __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(am >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(am), 0u));
-        const f3 q = pos + off;
-        rx[r] = q.x * 20.0f;
-        ry[r] = q.y * 20.0f;
-        rz[r] = q.z * 20.0f;
-        rt[r] = kFin + 2u * lane;
-        rx[r + 1] = q.x * 1.5f;
-        ry[r + 1] = q.y * 1.5f;
-        rz[r + 1] = q.z * 1.5f;
-        rt[r + 1] = kFin + 2u * lane + 1u;
-    }
-    if (staged >= 128u) noise_ring_rounds(cl, lds, lane, done, staged, false);
-
-    // ---- big craters :375-409 from the table ---------------------------------------------------
-    float crater_big = 0.0f;
-    uint32_t min_age = 0xffffu, n_dep = 0;
-    bool overflow = false;
-    for (uint32_t c = 0; c < count; ++c) {
-        const float4 r0 = craters[3 * c], r1 = craters[3 * c + 1], r2 = craters[3 * c + 2];
-        // the cell lies in the query's 4^3 neighbourhood: cell - floor(query) in {-1, 0, 1, 2}
-        const bool in = active && fabsf(r0.x - fl.x) < 2.0f && fabsf(r0.y - fl.y) < 2.0f && fabsf(r0.z - fl.z) < 2.0f;
-        bool dep = false;
-        float a1x = 0, a1y = 0, a1z = 0, a2x = 0, a2y = 0, a2z = 0, lin = 0, depth = 0;
-        if (in) {
-            const float size = r0.w, t = r1.w;
-            const f3 on = mk3(r1.x, r1.y, r1.z);
-            const f3 qv = query - on;
-            const float dist2 = norm_sq(qv);
-            const float idist = fast_rsq(fmaxf(dist2, 1e-30f));
-            const float dist = dist2 * idist;
-            const float c20 = 20.0f * (dist - size);
-            const float th = fast_tanh(c20);
-            const float rim = 0.9f * t * th * c20 * fast_rcp(fmaf(c20 * c20, c20, 0.02f));
-            depth = c20 > 1e-3f ? rim : th;
-            const bool outside = dist >= size;
-            lin = fmaxf(0.0f, 1.2f - dist * r2.y);
-            crater_big += -0.02f * depth;
-            if (!outside) min_age = min(min_age, __float_as_uint(r2.x));
-            dep = outside && lin > 0.0f;
-            if (dep && n_dep >= static_cast<uint32_t>(kLaneDeposits)) {
-                overflow = true;
-                dep = false;
-            }
-            const float k1 = 3.0f * size * idist, k2 = 40.0f * size * idist;
-            a1x = fmaf(k1, qv.x, on.x);
-            a1y = fmaf(k1, qv.y, on.y);
-            a1z = fmaf(k1, qv.z, on.z);
-            a2x = fmaf(k2, qv.x, on.x);
-            a2y = fmaf(k2, qv.y, on.y);
-            a2z = fmaf(k2, qv.z, on.z);
-        }
-        const unsigned long long dm = __ballot(dep);
-        if (dm) {
-            if (dep) {
-                const uint32_t call = staged + 2u * __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(dm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(dm), 0u));
-                const uint32_t s0 = call & (kRing - 1), s1 = (call + 1u) & (kRing - 1);
-                const uint32_t col = kCol + 4u * (64u * n_dep + lane);
-                rx[s0] = a1x;
-                ry[s0] = a1y;
-                rz[s0] = a1z;
-                rt[s0] = col;
-                rx[s1] = a2x;
-                ry[s1] = a2y;
-                rz[s1] = a2z;
-                rt[s1] = col + 1u;
-                lds[col + 2] = lin;
-                lds[col + 3] = depth;
-                ++n_dep;
-            }
-            staged += 2u * static_cast<uint32_t>(__popcll(dm));
-            if (staged - done >= 128u) noise_ring_rounds(cl, lds, lane, done, staged, false);
-        }
-    }
-
-    // ---- small craters :412-437 and tiny craters :440-463, cell by cell in the reference's order ----
-    float crater_small = -3.402823466e38f, tiny = 0.0f;
-    if (active) {
-#pragma unroll 1
-        for (int pass_no = 0; pass_no < 2; ++pass_no) {
-            const float scale = pass_no == 0 ? 10.0f : 60.0f;
-            const f3 q2 = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
-            const f3 f2 = mk3(floorf(q2.x), floorf(q2.y), floorf(q2.z));
-#pragma unroll 1
-            for (int cell = 0; cell < 8; ++cell) {
-                uint32_t h2;
-                f3 on2;
-                const f3 pt2 = scattered_cell(mk3(f2.x + static_cast<float>(cell >> 2), f2.y + static_cast<float>((cell >> 1) & 1), f2.z + static_cast<float>(cell & 1)), 0.5f, h2);
-                const bool pass2 = project_cell(pt2, off, scale, on2);
-                const float t2 = static_cast<float>(h2 & 0xffffu) * (1.0f / 65535.0f);
-                const uint32_t age2 = h2 >> 16;
-                const float d2 = sqrtf(norm_sq(q2 - on2));
-                const float size2 = pass_no == 0 ? fmaf(0.35f * t2, t2, 0.05f) : fmaf(0.35f, t2, 0.02f);
-                const float c50 = 50.0f * (d2 - size2);
-                const float th = fast_tanh(c50);
-                if (pass_no == 0) {
-                    if (pass2 && c50 < 0.0f && age2 <= min_age) {
-                        crater_small = fmaxf(crater_small, -0.005f * th);
-                        min_age = age2;
-                    }
-                } else if (pass2 && age2 <= min_age) {
-                    tiny = fmaxf(tiny, -0.004f * size2 * (-0.5f + 0.5f * th));
-                }
-            }
-        }
-    }
-
-    // ---- remaining noise() calls, then fallout and the final sum ----------------------------------
-    noise_ring_rounds(cl, lds, lane, done, staged, true);
-    if (active && !overflow) {
-        float fallout = 0.0f;
-        for (uint32_t j = 0; j < n_dep; ++j) {
-            const float4 e = *reinterpret_cast<const float4*>(lds + kCol + 4u * (64u * j + lane));
-            const float falloff = fast_exp2((2.0f + 3.0f * e.x) * fast_log2(e.z));
-            fallout += 0.1f * falloff * (0.2f + 0.4f * e.w) * e.y;
-        }
-        const float nf1 = lds[kFin + 2u * lane], nf2 = lds[kFin + 2u * lane + 1u];
-        out = s + fmaxf(crater_big, crater_small) + tiny + fallout + 0.01f * nf1 + 0.4f * nf2;
-        noise_calls = 2u * n_dep + 2u;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    return !overflow;
-}
-
-#pragma clang fp contract(off)
+#include "craterball.h"
 
 // Adds a per-lane counter into a 64-bit total with one atomic per wave.
 __device__ __forceinline__ void wave_add_total(unsigned long long* total, uint32_t v) {
@@ -1140,68 +621,10 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
                 if (result) break;
             }
         }
-        // (4) near-field evaluations: the wave serves its lanes' requests one after another, all 64
-        // lanes working on one point at a time
+        // (4) near-field evaluations for the lanes that need one
         const bool wants = state == MARCH && result == 0;
-        unsigned long long need = __ballot(wants);
         float d2 = 0.0f;
-        if (__popcll(need) >= kLaneThreshold) {
-            // most lanes wait for a value: one point per lane, primitive by primitive
-            unsigned long long todo = need;
-            while (todo) {
-                const int first = __ffsll(static_cast<long long>(todo)) - 1;
-                const uint32_t base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(crater_base), first));
-                const uint32_t count = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(crater_count), first));
-                const bool mine = wants && crater_base == base;
-                float v = 0.0f;
-                uint32_t calls = 0;
-                const bool ok = lane_near(reinterpret_cast<const float4*>(sc.craters) + 3u * base, count, cl, lds, mine, m.p, off, s, lane, v, calls);
-                if (mine && ok) {
-                    d2 = v;
-                    c_noise += calls;
-                    ++c_near;
-                }
-                todo &= ~__ballot(mine);
-                need &= ~__ballot(mine && ok);
-            }
-        }
-        while (__popcll(need) >= kCoopGroup) {
-            int src[kCoopGroup];
-            f3 P[kCoopGroup], O[kCoopGroup];
-            float S[kCoopGroup], val[kCoopGroup];
-            uint32_t calls[kCoopGroup];
-#pragma unroll
-            for (int g = 0; g < kCoopGroup; ++g) {
-                src[g] = __ffsll(static_cast<long long>(need)) - 1;
-                need &= need - 1ull;
-                P[g] = mk3(bcast_lane(m.p.x, src[g]), bcast_lane(m.p.y, src[g]), bcast_lane(m.p.z, src[g]));
-                O[g] = mk3(bcast_lane(off.x, src[g]), bcast_lane(off.y, src[g]), bcast_lane(off.z, src[g]));
-                S[g] = bcast_lane(s, src[g]);
-            }
-            coop_near<kCoopGroup>(cl, lds, O, P, S, lane, val, calls);
-#pragma unroll
-            for (int g = 0; g < kCoopGroup; ++g)
-                if (lane == static_cast<uint32_t>(src[g])) {
-                    d2 = val[g];
-                    c_noise += calls[g];
-                    ++c_near;
-                }
-        }
-        while (need) {
-            const int src = __ffsll(static_cast<long long>(need)) - 1;
-            need &= need - 1ull;
-            const f3 P[1] = {mk3(bcast_lane(m.p.x, src), bcast_lane(m.p.y, src), bcast_lane(m.p.z, src))};
-            const f3 O[1] = {mk3(bcast_lane(off.x, src), bcast_lane(off.y, src), bcast_lane(off.z, src))};
-            const float S[1] = {bcast_lane(s, src)};
-            float val[1];
-            uint32_t calls[1];
-            coop_near<1>(cl, lds, O, P, S, lane, val, calls);
-            if (lane == static_cast<uint32_t>(src)) {
-                d2 = val[0];
-                c_noise += calls[0];
-                ++c_near;
-            }
-        }
+        wave_near(sc.craters, cl, lds, lane, bp.lane_threshold, wants, m.p, off, s, crater_base, crater_count, d2, c_near, c_noise);
         if (wants) result = march_step(m, d2);
         // (5) finished marches fold into the ray's best hit and move on to the next primitive
         if (state == MARCH && result != 0) {
@@ -1314,27 +737,30 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
 }
 
 // SDF hits: the normal is a forward difference of four SDF evaluations (signedDistanceNormal,
-// include/Object.hpp:118-132); all four points lie in the near field of a hit.
+// include/Object.hpp:118-132): at the hit and at +delta along x, y, z.  The four lanes of a quad take
+// the four points of one hit, so a wave shades 16 hits per round; the quad's first lane then deflects
+// the path.  Hits are dealt to waves round-robin so that a short queue spreads over all waves.
 __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce, uint32_t max_bounces) {
     const uint32_t n = pb.counters[bounce].n_sdf_shade;
     uint32_t* next_queue = pb.queue[(bounce + 1) & 1];
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t rounds = (n + stride - 1) / stride;
-    uint32_t c_far = 0, c_near = 0, c_noise = 0;
-    __shared__ float s_coop[4 * kCoopLdsFloats];
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t per_round = n_waves * 16u;
+    const uint32_t rounds = (n + per_round - 1) / per_round;
+    uint32_t c_evals = 0, c_near = 0, c_noise = 0;
+    __shared__ __attribute__((aligned(16))) float s_near[4 * kNearLdsFloats];
     const uint32_t lane = __lane_id();
-    float* lds = s_coop + (threadIdx.x >> 6) * kCoopLdsFloats;
+    float* lds = s_near + (threadIdx.x >> 6) * kNearLdsFloats;
     const CoopLane cl = make_coop_lane(sc.noise_oct, lane);
-    // entries are dealt to waves round-robin (wave w, lane l takes entry w + l * n_waves) so that a short
-    // queue spreads over all waves: each wave evaluates its lanes' four points one after another
-    const uint32_t n_waves = stride >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t e = lane & 3u;   // which of the four points
+    const float delta = 1e-3f;
     for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t i = r * stride + wave + lane * n_waves;
+        const uint32_t i = r * per_round + wave + (lane >> 2) * n_waves;
         const bool valid = i < n;
-        uint32_t slot = 0;
+        uint32_t slot = 0, crater_base = 0, crater_count = 0;
         PrimRegs pr;
-        f3 wp = mk3(0, 0, 0), ld = mk3(0, 0, 0), lp = mk3(0, 0, 0), off = mk3(0, 0, 0);
+        f3 wp = mk3(0, 0, 0), ld = mk3(0, 0, 0), p = mk3(0, 0, 0), off = mk3(0, 0, 0);
+        float s = 0.0f;
         if (valid) {
             slot = pb.sdf_shade_queue[i];
             const uint32_t prim = static_cast<uint32_t>(pb.hit_key[slot] & 0xffffffffu);
@@ -1342,63 +768,22 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
             wp = ld3(pb.hit_pos[slot]);
             const f3 d = ld3(pb.ray_d[slot]);
             ld = lin_mul(pr.inv, d);
-            lp = aff_pos(pr.inv, wp);
+            const f3 lp = aff_pos(pr.inv, wp);
             off = mk3(pr.p[0], pr.p[1], pr.p[2]);
+            crater_base = __float_as_uint(pr.p[3]);
+            crater_count = __float_as_uint(pr.p[4]);
+            p = mk3(lp.x + (e == 1u ? delta : 0.0f), lp.y + (e == 2u ? delta : 0.0f), lp.z + (e == 3u ? delta : 0.0f));
+            s = norm(p) - 0.5f;
+            ++c_evals;
         }
-        // four SDF values per hit: at the hit and at +delta along x, y, z; the wave evaluates them one
-        // point at a time
-        const float delta = 1e-3f;
-        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        unsigned long long need = __ballot(valid);
-        while (need) {
-            const int src = __ffsll(static_cast<long long>(need)) - 1;
-            need &= need - 1ull;
-            const f3 P0 = mk3(bcast_lane(lp.x, src), bcast_lane(lp.y, src), bcast_lane(lp.z, src));
-            const f3 O0 = mk3(bcast_lane(off.x, src), bcast_lane(off.y, src), bcast_lane(off.z, src));
-            f3 P[4], O[4];
-            float S[4], val[4];
-            uint32_t calls[4] = {0, 0, 0, 0};
-            bool any_far = false;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                P[e] = mk3(P0.x + (e == 1 ? delta : 0.0f), P0.y + (e == 2 ? delta : 0.0f), P0.z + (e == 3 ? delta : 0.0f));
-                O[e] = O0;
-                S[e] = norm(P[e]) - 0.5f;
-                any_far = any_far || (static_cast<double>(S[e]) > 0.1);   // wave-uniform: the points are
-            }
-            uint32_t n_far = 0;
-            if (!any_far) {
-                coop_near<4>(cl, lds, O, P, S, lane, val, calls);   // the usual case: a hit lies in the near field
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    val[e] = S[e];
-                    if (static_cast<double>(S[e]) > 0.1) {
-                        ++n_far;
-                        continue;
-                    }
-                    const f3 P1[1] = {P[e]}, O1[1] = {O0};
-                    const float S1[1] = {S[e]};
-                    float v1[1];
-                    uint32_t c1[1];
-                    coop_near<1>(cl, lds, O1, P1, S1, lane, v1, c1);
-                    val[e] = v1[0];
-                    calls[e] = c1[0];
-                }
-            }
-            if (lane == static_cast<uint32_t>(src)) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = val[e];
-                    c_noise += calls[e];
-                }
-                c_far += n_far;
-                c_near += 4u - n_far;
-            }
-        }
+        // the far field returns the sphere distance itself (`sdf_sphere > 0.1` compares against a double literal)
+        const bool wants = valid && !(static_cast<double>(s) > 0.1);
+        float v = s;
+        wave_near(sc.craters, cl, lds, lane, bp.lane_threshold, wants, p, off, s, crater_base, crater_count, v, c_near, c_noise);
+        const float v0 = dpp_f<0x00>(0.0f, v), v1 = dpp_f<0x55>(0.0f, v), v2 = dpp_f<0xAA>(0.0f, v), v3 = dpp_f<0xFF>(0.0f, v);   // quad broadcasts
         bool alive = false;
-        if (valid) {
-            const f3 g = mk3(v[1] - v[0], v[2] - v[0], v[3] - v[0]) * (1.0f / delta);
+        if (valid && e == 0u) {
+            const f3 g = mk3(v1 - v0, v2 - v0, v3 - v0) * (1.0f / delta);
             const f3 nrm = unit(g);
             const uint32_t s_local = slot / bp.n_pix;
             Rng rng(bp.seed, slot - s_local * bp.n_pix, bp.first_sample + s_local, 1u + bounce);
@@ -1409,7 +794,7 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.totals->sdf_shades, static_cast<unsigned long long>(n));
     if (rounds) {
-        wave_add_total(&pb.totals->shade_near_evals, c_near + c_far);
+        wave_add_total(&pb.totals->shade_near_evals, c_evals);
         wave_add_total(&pb.totals->shade_noise_calls, c_noise);
     }
 }

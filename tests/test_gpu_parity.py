@@ -254,3 +254,32 @@ def test_config5_mirrors_glass_emitters_16_bounces(ctx, alg, oracle):
     gimg, gst = ctx.render(ctx.upload(flat), cam, 48, 48, 16, 4, seed=2)
     assert abs(gst["rays"] - wst["rays"]) <= 2e-3 * wst["rays"] and wst["rays"] > 1.5 * wst["paths"]
     assert (np.abs(wimg - gimg) <= 1e-4 * np.maximum(1.0, np.abs(wimg))).all(axis=2).mean() >= 0.99
+
+
+def test_sdf_value_is_independent_of_evaluator():
+    """A near-field SDF value may be computed by a whole wave for one point or by one lane per point,
+    depending on how many lanes of a wave wait together (timing).  Both must agree bit for bit: the
+    same frame with either evaluator forced is identical, march counts included."""
+    import os
+    alg = api.HostAlgebra()
+    flat = S.demo_scene(alg)
+    cam = G.demo_closeup_camera(alg)
+    frames = []
+    old = os.environ.get("MIPT_LANE_THRESHOLD")
+    try:
+        for threshold in ("1", "65", "24"):
+            os.environ["MIPT_LANE_THRESHOLD"] = threshold
+            c = api.Context()
+            img, st = c.render(c.upload(flat), cam, 96, 96, 8, 8, seed=11)
+            frames.append((img, st))
+            c.close()
+    finally:
+        if old is None:
+            os.environ.pop("MIPT_LANE_THRESHOLD", None)
+        else:
+            os.environ["MIPT_LANE_THRESHOLD"] = old
+    for img, st in frames[1:]:
+        assert np.array_equal(img, frames[0][0])
+        for key in ("rays", "sdf_rays", "sdf_shades", "sdf_near_evals", "sdf_far_evals", "sdf_noise_calls", "shade_noise_calls"):
+            assert st[key] == frames[0][1][key], key
+    assert frames[0][1]["sdf_near_evals"] > 10000
