@@ -75,16 +75,24 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-size_t batch_path_budget() {
-    // Paths in flight per sample batch; the per-slot state is 88 bytes plus 16 bytes of queues, so the
-    // default working set is ~14 GB of the 288 GB.  Large batches matter: every bounce of every batch
-    // ends in a latency-bound tail (the longest SDF march), and fewer batches mean fewer tails.
-    size_t budget = size_t(128) << 20;
+constexpr size_t kBytesPerSlot = 4 * 16 + 8 + 16 + 4 * 4;   // rays, attenuation, radiance, hit key, hit position, four queues
+constexpr size_t kMaxSlots = (size_t(1) << 31) - 256;      // slot indices are 32-bit
+
+// Paths in flight per sample batch.  Large batches matter: every bounce of every batch ends in a
+// latency-bound tail (the longest SDF marches, a few rays on an otherwise idle chip), and fewer batches
+// mean fewer tails -- the demo frame at 1080p, 1024 spp runs 1.4x faster as one batch of 2.1 G paths
+// (221 GB) than as sixteen.  The default therefore takes up to 80 % of the memory that is free on the
+// device; MIPT_BATCH_PATHS overrides it.
+size_t batch_path_budget(const mipt_ctx* c) {
     if (const char* e = std::getenv("MIPT_BATCH_PATHS")) {
         const long long v = std::atoll(e);
-        if (v > 0) budget = static_cast<size_t>(v);
+        if (v > 0) return std::min(static_cast<size_t>(v), kMaxSlots);
     }
-    return budget;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return size_t(128) << 20;
+    free_b += c->slots_cap * kBytesPerSlot;   // the arena is replaced when it has to grow
+    const size_t budget = free_b / 10 * 8 / kBytesPerSlot;
+    return std::min(std::max(budget, size_t(1) << 20), kMaxSlots);
 }
 
 int ensure_slots(mipt_ctx* c, size_t slots) {
@@ -211,12 +219,19 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
     if (n_pix > (size_t(1) << 31)) return MIPT_ERR_TOO_LARGE;
     HIP_TRY(c, hipSetDevice(c->device));
     c->cancel.store(0);
-    const size_t budget = batch_path_budget();
-    uint32_t per_batch = static_cast<uint32_t>(std::max<size_t>(1, budget / n_pix));
-    per_batch = std::min(per_batch, st->spp);
-    if (n_pix * per_batch > (size_t(1) << 31)) return MIPT_ERR_TOO_LARGE;
-    int rc = ensure_slots(c, n_pix * per_batch);
-    if (rc != MIPT_OK) return rc;
+    // equal batches, as few as the memory budget allows; on an allocation failure try smaller ones
+    size_t per_batch_max = std::max<size_t>(1, batch_path_budget(c) / n_pix);
+    uint32_t per_batch = 0;
+    for (;;) {
+        const size_t n_batches = (st->spp + per_batch_max - 1) / per_batch_max;
+        per_batch = static_cast<uint32_t>((st->spp + n_batches - 1) / n_batches);
+        if (n_pix * per_batch > kMaxSlots) return MIPT_ERR_TOO_LARGE;
+        const int rc = ensure_slots(c, n_pix * per_batch);
+        if (rc == MIPT_OK) break;
+        if (rc != MIPT_ERR_OUT_OF_MEMORY || per_batch == 1) return rc;
+        (void)hipGetLastError();
+        per_batch_max = std::max<size_t>(1, per_batch / 2);
+    }
     const CameraRec cr = pack_camera(*cam);
     HIP_TRY(c, hipMemsetAsync(c->pb.totals, 0, sizeof(Totals), c->stream));
     c->ev_used = 0;

@@ -341,10 +341,21 @@ __device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, float4
     wave_lds_fence();
 
     // ---- noise() as (point, octave) tasks: 8 points per round ---------------------------------
-    for (uint32_t first = 0; first < n_pts; first += 8u) {
-        const uint32_t slot = first + (lane >> 3);
-        const float v = noise_octaves(cl, px[slot], py[slot], pz[slot]);   // slots past n_pts hold stale but finite data
-        if ((lane & 7u) == 0u) pv[slot] = v;
+    // (the next round's arguments are fetched before this round computes, so LDS latency stays hidden;
+    // slots past n_pts hold stale data whose values are never used)
+    {
+        uint32_t slot = lane >> 3;
+        float x = px[slot], y = py[slot], z = pz[slot];
+        for (uint32_t first = 0; first < n_pts; first += 8u) {
+            const uint32_t next = slot + 8u < static_cast<uint32_t>(kCoopPts) ? slot + 8u : slot;
+            const float nx = px[next], ny = py[next], nz = pz[next];
+            const float v = noise_octaves(cl, x, y, z);
+            if ((lane & 7u) == 0u) pv[slot] = v;
+            slot = next;
+            x = nx;
+            y = ny;
+            z = nz;
+        }
     }
     wave_lds_fence();
 
@@ -393,8 +404,9 @@ __device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, float4
 }
 
 // =============================================================================================
-// lane_near: one point per lane.  A wave-uniform loop walks the ball's crater table (records in scalar
-// registers), the small and tiny craters go cell by cell, and only noise() stays cooperative: every
+// lane_near: one point per lane.  A wave-uniform loop walks the ball's crater table (lane c holds crater
+// c; the loop reads it into scalar registers with readlane, so no step waits for memory), the small and
+// tiny craters go cell by cell, and only noise() stays cooperative: every
 // lane stages the arguments of its calls in a ring in LDS, and rounds of 8 calls x 8 octaves drain the
 // ring whenever half of it is full, writing each value to the LDS slot its owner named.
 // =============================================================================================
@@ -409,22 +421,37 @@ __device__ __forceinline__ void noise_ring_rounds(const CoopLane& cl, float* lds
     const float* ry = lds + kRing;
     const float* rz = lds + 2 * kRing;
     const uint32_t* rt = reinterpret_cast<const uint32_t*>(lds + 3 * kRing);
+    // the next round's arguments are fetched before this round computes, so LDS latency stays hidden
+    uint32_t call = done + (lane >> 3);
+    uint32_t slot = call & (kRing - 1);
+    float x = rx[slot], y = ry[slot], z = rz[slot];
+    uint32_t target = rt[slot];
     while (flush_all ? done < staged : done + 8u <= staged) {
-        const uint32_t call = done + (lane >> 3);
-        const uint32_t slot = call & (kRing - 1);
-        const uint32_t target = rt[slot];
-        const float v = noise_octaves(cl, rx[slot], ry[slot], rz[slot]);
+        const uint32_t next = (call + 8u) & (kRing - 1);
+        const float nx = rx[next], ny = ry[next], nz = rz[next];
+        const uint32_t next_target = rt[next];
+        const float v = noise_octaves(cl, x, y, z);
         if ((lane & 7u) == 0u && call < staged) lds[target] = v;
         done += 8u;
+        call += 8u;
+        x = nx;
+        y = ny;
+        z = nz;
+        target = next_target;
     }
     if (done > staged) done = staged;
     wave_lds_fence();
 }
 
+__device__ __forceinline__ float4 bcast_lane4(float4 v, int lane) {
+    return make_float4(bcast_lane(v.x, lane), bcast_lane(v.y, lane), bcast_lane(v.z, lane), bcast_lane(v.w, lane));
+}
+
 // Evaluates the near field at `pos` for every lane with `active` set; all 64 lanes must call and the
-// crater table (`count` <= 64 records) is the same for all of them.  Returns false for a lane whose
-// point has more fallout deposits than a lane can hold; its `out` is then not written.
-__device__ __forceinline__ bool lane_near(const float4* __restrict__ craters, uint32_t count, const CoopLane& cl, float* lds, bool active, f3 pos,
+// crater table (lane c holds crater c in t0..t2, `count` <= 64) is the same for all of them.  Returns
+// false for a lane whose point has more fallout deposits than a lane can hold; its `out` is then not
+// written.
+__device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, uint32_t count, const CoopLane& cl, float* lds, bool active, f3 pos,
                                           f3 off, float s, uint32_t lane, float& out, uint32_t& noise_calls) {
     float* rx = lds;
     float* ry = lds + kRing;
@@ -456,10 +483,15 @@ __device__ __forceinline__ bool lane_near(const float4* __restrict__ craters, ui
     uint32_t min_age = 0xffffu, n_dep = 0;
     bool overflow = false;
     for (uint32_t c = 0; c < count; ++c) {
-        const float4 r0 = craters[3 * c], r1 = craters[3 * c + 1], r2 = craters[3 * c + 2];
+        const int ci = static_cast<int>(c);
+        float4 r0 = make_float4(bcast_lane(t0.x, ci), bcast_lane(t0.y, ci), bcast_lane(t0.z, ci), 0.0f);
         const bool in = active && crater_in_reach(r0, fl);
+        if (!__ballot(in)) continue;
+        r0.w = bcast_lane(t0.w, ci);
+        const float4 r1 = bcast_lane4(t1, ci);
+        const float4 r2 = make_float4(bcast_lane(t2.x, ci), bcast_lane(t2.y, ci), 0.0f, 0.0f);
         bool dep = false;
-        BigCrater b;
+        BigCrater b = {};
         if (in) {
             b = big_crater(query, r0, r1, r2);
             big_fix += big_crater_fix(b);
@@ -522,9 +554,12 @@ __device__ __forceinline__ bool lane_near(const float4* __restrict__ craters, ui
     noise_ring_rounds(cl, lds, lane, done, staged, true);
     if (active && !overflow) {
         int fallout = 0;
+        float4 e = *reinterpret_cast<const float4*>(lds + kCol + 4u * lane);
         for (uint32_t j = 0; j < n_dep; ++j) {
-            const float4 e = *reinterpret_cast<const float4*>(lds + kCol + 4u * (64u * j + lane));
+            const uint32_t jn = j + 1u < static_cast<uint32_t>(kLaneDeposits) ? j + 1u : j;
+            const float4 en = *reinterpret_cast<const float4*>(lds + kCol + 4u * (64u * jn + lane));
             fallout += fallout_fix(e.x, e.y, e.z, e.w);
+            e = en;
         }
         const float nf1 = lds[kFin + 2u * lane], nf2 = lds[kFin + 2u * lane + 1u];
         out = near_total(s, big_fix, crater_small, tiny, fallout, nf1, nf2);
@@ -550,24 +585,24 @@ __device__ __forceinline__ void wave_near(const float* crater_table, const CoopL
         const bool mine = wants && crater_base == base;
         unsigned long long need = __ballot(mine);
         todo &= ~need;
+        // lane c holds crater c of the ball's table; lanes past the table hold a cell out of anyone's reach
         const float4* table = reinterpret_cast<const float4*>(crater_table) + 3u * base;
+        float4 r0 = make_float4(1e30f, 1e30f, 1e30f, 1.0f), r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r2 = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
+        if (lane < count) {
+            r0 = table[3u * lane];
+            r1 = table[3u * lane + 1u];
+            r2 = table[3u * lane + 2u];
+        }
         if (static_cast<uint32_t>(__popcll(need)) >= lane_threshold) {
             float v = 0.0f;
             uint32_t calls = 0;
-            const bool ok = lane_near(table, count, cl, lds, mine, p, off, s, lane, v, calls);
+            const bool ok = lane_near(r0, r1, r2, count, cl, lds, mine, p, off, s, lane, v, calls);
             if (mine && ok) {
                 value = v;
                 n_noise += calls;
                 ++n_evals;
             }
             need &= ~__ballot(mine && ok);
-        }
-        if (!need) continue;
-        float4 r0 = make_float4(1e30f, 1e30f, 1e30f, 1.0f), r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r2 = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
-        if (lane < count) {
-            r0 = table[3u * lane];
-            r1 = table[3u * lane + 1u];
-            r2 = table[3u * lane + 2u];
         }
         while (__popcll(need) >= kCoopGroup) {
             int src[kCoopGroup];
