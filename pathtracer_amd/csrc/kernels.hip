@@ -286,19 +286,16 @@ __device__ __forceinline__ bool slab(f3 o, f3 inv_d, const float* lo, const floa
 }
 
 // =============================================================================================
-// Camera ray of one path slot: Renderer::doWork's sample set-up (src/Renderer.cpp:72-94) +
-// Camera::getViewRay (src/Camera.cpp:65-81).  slot = sample_in_batch * n_pix + pixel, so a wave covers
-// 64 neighbouring pixels of one sample.
+// Camera ray of sample `sample` of pixel (x, y): Renderer::doWork's sample set-up (src/Renderer.cpp:72-94)
+// + Camera::getViewRay (src/Camera.cpp:65-81).  (sx0, sy0) = (x / (w - 1), y / (h - 1)) is the same for
+// every sample of the pixel and is passed in.
 // =============================================================================================
-__device__ __forceinline__ void camera_ray(const CameraRec& cam, const BatchParams& bp, uint32_t slot, f3& pos, f3& dir) {
+__device__ __forceinline__ void camera_ray(const CameraRec& cam, const BatchParams& bp, uint32_t pix, uint32_t sample, float sx0, float sy0, f3& pos,
+                                           f3& dir) {
     const float max_w = static_cast<float>(bp.width - 1), max_h = static_cast<float>(bp.height - 1);
     const float dx = 1.0f / max_w, dy = 1.0f / max_h;
-    const uint32_t s_local = slot / bp.n_pix;
-    const uint32_t pix = slot - s_local * bp.n_pix;
-    const uint32_t y = pix / bp.width, x = pix - y * bp.width;
-    Rng rng(bp.seed, pix, bp.first_sample + s_local, 0u);
-    float sx = static_cast<float>(x) / max_w;
-    float sy = static_cast<float>(y) / max_h;
+    Rng rng(bp.seed, pix, sample, 0u);
+    float sx = sx0, sy = sy0;
     if (!(bp.flags & 1u)) {
         sx = sx + rng.uniform(-0.5f * dx, 0.5f * dx);
         sy = sy + rng.uniform(-0.5f * dy, 0.5f * dy);
@@ -328,17 +325,17 @@ __device__ __forceinline__ void camera_ray(const CameraRec& cam, const BatchPara
 // reference ranks them; boxes are culled in ray-parameter units, t / |d|^2, with a relative and an
 // absolute margin.  Returns the cull limit for the SDF box tests that follow.
 // =============================================================================================
-__device__ __forceinline__ float closest_analytic(const SceneDev& sc, int* stack, f3 o, f3 d, f3 inv_d, unsigned long long& best, f3& best_pos) {
+// (ra..re are the four float4 of node 0, which a kernel loads once for all its rays.)
+__device__ __forceinline__ float closest_analytic(const SceneDev& sc, float4 ra, float4 rb, float4 rc, float4 re, int* stack, f3 o, f3 d, f3 inv_d,
+                                                  unsigned long long& best, f3& best_pos) {
     const float inv_len2 = 1.0f / norm_sq(d);
     float limit = 3.0e38f;
     best = kMissKey;
     best_pos = mk3(0.0f, 0.0f, 0.0f);
     if (!sc.nodes) return limit;
     int sp = 0;
-    int cur = 0;
+    float4 a = ra, b = rb, c = rc, e = re;
     for (;;) {
-        const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
-        const float4 a = np[0], b = np[1], c = np[2], e = np[3];
         const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y};
         const float lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
         int c0 = __float_as_int(e.x), c1 = __float_as_int(e.y);
@@ -384,18 +381,23 @@ __device__ __forceinline__ float closest_analytic(const SceneDev& sc, int* stack
             --sp;
             next = stack[sp * 256];
         }
-        cur = next;
+        const float4* np = reinterpret_cast<const float4*>(sc.nodes + next);
+        a = np[0];
+        b = np[1];
+        c = np[2];
+        e = np[3];
     }
     return limit;
 }
 
 // Does the ray reach any SDF primitive's box before its best analytic hit?
-__device__ __forceinline__ bool reaches_sdf_box(const SceneDev& sc, f3 o, f3 inv_d, float limit) {
-    bool any = false;
-    for (uint32_t k = 0; k < sc.n_sdf; ++k) {
-        float tn;
-        any = any || slab(o, inv_d, sc.sdf_boxes[k].lo, sc.sdf_boxes[k].hi, limit, tn);
-    }
+// (lo0, hi0 are the corners of sdf_boxes[0], which a kernel loads once for all its rays.)
+__device__ __forceinline__ bool reaches_sdf_box(const SceneDev& sc, f3 lo0, f3 hi0, f3 o, f3 inv_d, float limit) {
+    if (sc.n_sdf == 0) return false;
+    float tn;
+    const float lo[3] = {lo0.x, lo0.y, lo0.z}, hi[3] = {hi0.x, hi0.y, hi0.z};
+    bool any = slab(o, inv_d, lo, hi, limit, tn);
+    for (uint32_t k = 1; k < sc.n_sdf; ++k) any = any || slab(o, inv_d, sc.sdf_boxes[k].lo, sc.sdf_boxes[k].hi, limit, tn);
     return any;
 }
 
@@ -411,38 +413,96 @@ __device__ __forceinline__ void wave_append_active(uint32_t value, uint32_t* cou
     queue[base + rank] = value;
 }
 
+// A wave's pending queue entries, gathered in LDS so that one atomic reserves room for hundreds of them:
+// atomics on one counter from all over the chip are served one at a time (tens of nanoseconds each),
+// which would otherwise bound a kernel whose waves append every iteration.
+constexpr uint32_t kPendCap = 1024;
+struct PendingQueue {
+    uint32_t* buf;      // kPendCap entries of this wave in LDS
+    uint32_t count;     // wave-uniform
+};
+__device__ __forceinline__ void pending_flush(PendingQueue& q, uint32_t* counter, uint32_t* queue) {
+    if (q.count == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t lane = __lane_id();
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(counter, q.count);
+    base = __shfl(base, 0);
+    for (uint32_t i = lane; i < q.count; i += 64u) queue[base + i] = q.buf[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    q.count = 0;
+}
+// All 64 lanes call; lanes with `pred` append `value`.
+__device__ __forceinline__ void pending_push(PendingQueue& q, bool pred, uint32_t value, uint32_t* counter, uint32_t* queue) {
+    const unsigned long long m = __ballot(pred);
+    if (!m) return;
+    if (q.count + 64u > kPendCap) pending_flush(q, counter, queue);
+    if (pred) q.buf[q.count + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u))] = value;
+    q.count += static_cast<uint32_t>(__popcll(m));
+}
+
 // =============================================================================================
 // generate + first extend, fused: a primary ray lives in registers from the camera to its closest hit.
 // Only paths that hit an analytic primitive or reach an SDF box are written to HBM (ray, hit) and
-// queued for the stages that follow; on the demo scene that is ~5 % of the paths, the rest cost no
+// queued for the stages that follow; on the demo scene that is ~10 % of the paths, the rest cost no
 // memory traffic at all.
 // =============================================================================================
 template <int STACK>
 __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev sc, BatchParams bp, PathBuffers pb) {
     __shared__ int s_stack[STACK * 256];
+    __shared__ uint32_t s_pend[2 * 4 * kPendCap];
     int* stack = s_stack + threadIdx.x;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    uint32_t n_sdf_rays = 0;
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < bp.n_slots; slot += stride) {
-        f3 o, d;
-        camera_ray(cam, bp, slot, o, d);
-        const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        unsigned long long best;
-        f3 best_pos;
-        const float limit = closest_analytic(sc, stack, o, d, inv_d, best, best_pos);
-        const bool wants_sdf = reaches_sdf_box(sc, o, inv_d, limit);
-        if (best != kMissKey || wants_sdf) {
-            pb.ray_o[slot] = st4(o);
-            pb.ray_d[slot] = st4(d);
-            pb.hit_key[slot] = best;
-            pb.hit_pos[slot] = st4(best_pos);
-            wave_append_active(slot, &pb.counters[0].n_live, pb.queue[0]);
-        }
-        if (wants_sdf) {
-            wave_append_active(slot, &pb.counters[0].n_sdf, pb.sdf_queue);
-            ++n_sdf_rays;
-        }
+    PendingQueue live{s_pend + (threadIdx.x >> 6) * kPendCap, 0u}, to_sdf{s_pend + (4u + (threadIdx.x >> 6)) * kPendCap, 0u};
+    // a thread owns one pixel and walks a stripe of its samples: blockIdx.y, blockIdx.y + gridDim.y, ...
+    // (threads past the image run along with no work so that the wave-wide steps stay aligned)
+    const uint32_t pix_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_image = pix_raw < bp.n_pix;
+    const uint32_t pix = in_image ? pix_raw : bp.n_pix - 1u;
+    const uint32_t samples = bp.n_slots / bp.n_pix;
+    const uint32_t y = pix / bp.width, x = pix - y * bp.width;
+    const float sx0 = static_cast<float>(x) / static_cast<float>(bp.width - 1);
+    const float sy0 = static_cast<float>(y) / static_cast<float>(bp.height - 1);
+    float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra, re = ra;
+    if (sc.nodes) {
+        const float4* np = reinterpret_cast<const float4*>(sc.nodes);
+        ra = np[0];
+        rb = np[1];
+        rc = np[2];
+        re = np[3];
     }
+    f3 box_lo = mk3(0, 0, 0), box_hi = mk3(0, 0, 0);
+    if (sc.n_sdf) {
+        box_lo = mk3(sc.sdf_boxes[0].lo[0], sc.sdf_boxes[0].lo[1], sc.sdf_boxes[0].lo[2]);
+        box_hi = mk3(sc.sdf_boxes[0].hi[0], sc.sdf_boxes[0].hi[1], sc.sdf_boxes[0].hi[2]);
+    }
+    uint32_t n_sdf_rays = 0;
+    for (uint32_t s_local = blockIdx.y; s_local < samples; s_local += gridDim.y) {
+        const uint32_t slot = s_local * bp.n_pix + pix;
+        bool keep = false, wants_sdf = false;
+        if (in_image) {
+            f3 o, d;
+            camera_ray(cam, bp, pix, bp.first_sample + s_local, sx0, sy0, o, d);
+            const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            unsigned long long best;
+            f3 best_pos;
+            const float limit = closest_analytic(sc, ra, rb, rc, re, stack, o, d, inv_d, best, best_pos);
+            wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, o, inv_d, limit);
+            keep = best != kMissKey || wants_sdf;
+            if (keep) {
+                pb.ray_o[slot] = st4(o);
+                pb.ray_d[slot] = st4(d);
+                pb.hit_key[slot] = best;
+                pb.hit_pos[slot] = st4(best_pos);
+            }
+        }
+        pending_push(live, keep, slot, &pb.counters[0].n_live, pb.queue[0]);
+        pending_push(to_sdf, wants_sdf, slot, &pb.counters[0].n_sdf, pb.sdf_queue);
+        n_sdf_rays += wants_sdf ? 1u : 0u;
+    }
+    pending_flush(live, &pb.counters[0].n_live, pb.queue[0]);
+    pending_flush(to_sdf, &pb.counters[0].n_sdf, pb.sdf_queue);
     if (n_sdf_rays) atomicAdd(&pb.totals->sdf_rays, static_cast<unsigned long long>(n_sdf_rays));
 }
 
@@ -457,6 +517,19 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
     const uint32_t* queue = pb.queue[bounce & 1];
     const uint32_t stride = gridDim.x * blockDim.x;
     int* stack = s_stack + threadIdx.x;
+    float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra, re = ra;
+    if (sc.nodes) {
+        const float4* np = reinterpret_cast<const float4*>(sc.nodes);
+        ra = np[0];
+        rb = np[1];
+        rc = np[2];
+        re = np[3];
+    }
+    f3 box_lo = mk3(0, 0, 0), box_hi = mk3(0, 0, 0);
+    if (sc.n_sdf) {
+        box_lo = mk3(sc.sdf_boxes[0].lo[0], sc.sdf_boxes[0].lo[1], sc.sdf_boxes[0].lo[2]);
+        box_hi = mk3(sc.sdf_boxes[0].hi[0], sc.sdf_boxes[0].hi[1], sc.sdf_boxes[0].hi[2]);
+    }
     uint32_t n_sdf_rays = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t slot = queue[i];
@@ -465,10 +538,10 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
         const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         unsigned long long best;
         f3 best_pos;
-        const float limit = closest_analytic(sc, stack, o, d, inv_d, best, best_pos);
+        const float limit = closest_analytic(sc, ra, rb, rc, re, stack, o, d, inv_d, best, best_pos);
         pb.hit_key[slot] = best;
         pb.hit_pos[slot] = st4(best_pos);
-        if (reaches_sdf_box(sc, o, inv_d, limit)) {
+        if (reaches_sdf_box(sc, box_lo, box_hi, o, inv_d, limit)) {
             wave_append_active(slot, &pb.counters[bounce].n_sdf, pb.sdf_queue);
             ++n_sdf_rays;
         }
@@ -943,7 +1016,10 @@ static inline uint32_t grid_for(size_t n, uint32_t cap = 256u * 32u) {
 }
 
 void launch_generate_extend(hipStream_t st, const CameraRec& cam, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, int bvh_depth) {
-    const dim3 grid(grid_for(bp.n_slots, 256u * 32u)), block(256);
+    // one thread per pixel; enough sample stripes to fill the chip when the image is small
+    const uint32_t bx = (bp.n_pix + 255u) / 256u, samples = bp.n_slots / bp.n_pix;
+    const uint32_t by = std::max(1u, std::min(samples, (4096u + bx - 1u) / bx));
+    const dim3 grid(bx, by), block(256);
     if (bvh_depth <= 8) hipLaunchKernelGGL(k_generate_extend<8>, grid, block, 0, st, cam, sc, bp, pb);
     else if (bvh_depth <= 24) hipLaunchKernelGGL(k_generate_extend<24>, grid, block, 0, st, cam, sc, bp, pb);
     else if (bvh_depth <= 40) hipLaunchKernelGGL(k_generate_extend<40>, grid, block, 0, st, cam, sc, bp, pb);
