@@ -401,24 +401,19 @@ __device__ __forceinline__ bool reaches_sdf_box(const SceneDev& sc, f3 lo0, f3 h
     return any;
 }
 
-// Appends `value` for the calling lanes (call it inside the branch that decided to append): one atomic
-// per wave, ranks by popcount of the lanes below.
-__device__ __forceinline__ void wave_append_active(uint32_t value, uint32_t* counter, uint32_t* queue) {
-    const unsigned long long m = __ballot(1);
-    const uint32_t lane = __lane_id();
-    const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
-    uint32_t base = 0;
-    if (rank == 0) base = atomicAdd(counter, static_cast<uint32_t>(__popcll(m)));
-    base = __shfl(base, __ffsll(static_cast<long long>(m)) - 1);
-    queue[base + rank] = value;
+// Adds a per-lane counter into a 64-bit total with one atomic per wave.
+__device__ __forceinline__ void wave_add_total(unsigned long long* total, uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (__lane_id() == 0 && v) atomicAdd(total, static_cast<unsigned long long>(v));
 }
 
 // A wave's pending queue entries, gathered in LDS so that one atomic reserves room for hundreds of them:
 // atomics on one counter from all over the chip are served one at a time (tens of nanoseconds each),
 // which would otherwise bound a kernel whose waves append every iteration.
-constexpr uint32_t kPendCap = 1024;
 struct PendingQueue {
-    uint32_t* buf;      // kPendCap entries of this wave in LDS
+    uint32_t* buf;      // `cap` entries of this wave in LDS
+    uint32_t cap;       // at least 64
     uint32_t count;     // wave-uniform
 };
 __device__ __forceinline__ void pending_flush(PendingQueue& q, uint32_t* counter, uint32_t* queue) {
@@ -438,7 +433,7 @@ __device__ __forceinline__ void pending_flush(PendingQueue& q, uint32_t* counter
 __device__ __forceinline__ void pending_push(PendingQueue& q, bool pred, uint32_t value, uint32_t* counter, uint32_t* queue) {
     const unsigned long long m = __ballot(pred);
     if (!m) return;
-    if (q.count + 64u > kPendCap) pending_flush(q, counter, queue);
+    if (q.count + 64u > q.cap) pending_flush(q, counter, queue);
     if (pred) q.buf[q.count + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u))] = value;
     q.count += static_cast<uint32_t>(__popcll(m));
 }
@@ -452,9 +447,10 @@ __device__ __forceinline__ void pending_push(PendingQueue& q, bool pred, uint32_
 template <int STACK>
 __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev sc, BatchParams bp, PathBuffers pb) {
     __shared__ int s_stack[STACK * 256];
-    __shared__ uint32_t s_pend[2 * 4 * kPendCap];
+    constexpr uint32_t kCap = 1024;
+    __shared__ uint32_t s_pend[2 * 4 * kCap];
     int* stack = s_stack + threadIdx.x;
-    PendingQueue live{s_pend + (threadIdx.x >> 6) * kPendCap, 0u}, to_sdf{s_pend + (4u + (threadIdx.x >> 6)) * kPendCap, 0u};
+    PendingQueue live{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u}, to_sdf{s_pend + (4u + (threadIdx.x >> 6)) * kCap, kCap, 0u};
     // a thread owns one pixel and walks a stripe of its samples: blockIdx.y, blockIdx.y + gridDim.y, ...
     // (threads past the image run along with no work so that the wave-wide steps stay aligned)
     const uint32_t pix_raw = blockIdx.x * blockDim.x + threadIdx.x;
@@ -503,7 +499,7 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
     }
     pending_flush(live, &pb.counters[0].n_live, pb.queue[0]);
     pending_flush(to_sdf, &pb.counters[0].n_sdf, pb.sdf_queue);
-    if (n_sdf_rays) atomicAdd(&pb.totals->sdf_rays, static_cast<unsigned long long>(n_sdf_rays));
+    wave_add_total(&pb.totals->sdf_rays, n_sdf_rays);
 }
 
 // =============================================================================================
@@ -513,6 +509,9 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
 template <int STACK>
 __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
     __shared__ int s_stack[STACK * 256];
+    constexpr uint32_t kCap = 128;
+    __shared__ uint32_t s_pend[4 * kCap];
+    PendingQueue to_sdf{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u};
     const uint32_t n = pb.counters[bounce].n_live;
     const uint32_t* queue = pb.queue[bounce & 1];
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -531,32 +530,32 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
         box_hi = mk3(sc.sdf_boxes[0].hi[0], sc.sdf_boxes[0].hi[1], sc.sdf_boxes[0].hi[2]);
     }
     uint32_t n_sdf_rays = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t slot = queue[i];
-        const f3 o = ld3(pb.ray_o[slot]);
-        const f3 d = ld3(pb.ray_d[slot]);
-        const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        unsigned long long best;
-        f3 best_pos;
-        const float limit = closest_analytic(sc, ra, rb, rc, re, stack, o, d, inv_d, best, best_pos);
-        pb.hit_key[slot] = best;
-        pb.hit_pos[slot] = st4(best_pos);
-        if (reaches_sdf_box(sc, box_lo, box_hi, o, inv_d, limit)) {
-            wave_append_active(slot, &pb.counters[bounce].n_sdf, pb.sdf_queue);
-            ++n_sdf_rays;
+    // all lanes of a wave run the same number of rounds so that the wave-wide steps line up
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool wants_sdf = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = queue[i];
+            const f3 o = ld3(pb.ray_o[slot]);
+            const f3 d = ld3(pb.ray_d[slot]);
+            const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            unsigned long long best;
+            f3 best_pos;
+            const float limit = closest_analytic(sc, ra, rb, rc, re, stack, o, d, inv_d, best, best_pos);
+            pb.hit_key[slot] = best;
+            pb.hit_pos[slot] = st4(best_pos);
+            wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, o, inv_d, limit);
         }
+        pending_push(to_sdf, wants_sdf, slot, &pb.counters[bounce].n_sdf, pb.sdf_queue);
+        n_sdf_rays += wants_sdf ? 1u : 0u;
     }
-    if (n_sdf_rays) atomicAdd(&pb.totals->sdf_rays, static_cast<unsigned long long>(n_sdf_rays));
+    pending_flush(to_sdf, &pb.counters[bounce].n_sdf, pb.sdf_queue);
+    wave_add_total(&pb.totals->sdf_rays, n_sdf_rays);
 }
 
 #include "craterball.h"
-
-// Adds a per-lane counter into a 64-bit total with one atomic per wave.
-__device__ __forceinline__ void wave_add_total(unsigned long long* total, uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (__lane_id() == 0 && v) atomicAdd(total, static_cast<unsigned long long>(v));
-}
 
 // =============================================================================================
 // sdf_march: SDFObjectCRTP::hitLocalRay (include/Object.hpp:135-167) as a per-lane state machine.
@@ -599,7 +598,8 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
     uint32_t* head = &pb.counters[bounce].sdf_head;
     constexpr int IDLE = 0, SETUP = 1, MARCH = 2;
     int state = IDLE;
-    bool exhausted = false;
+    uint32_t range_next = 0, range_end = 0, seen = 0;   // this wave's reserved queue entries; the cursor as last seen
+    bool drained = false;                               // the queue has been handed out completely
     uint32_t slot = 0, k = 0, prim = 0, crater_base = 0, crater_count = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv_d = mk3(0, 0, 0), off = mk3(0, 0, 0), best_pos = mk3(0, 0, 0);
     float inv_len2 = 0.0f, limit = 0.0f;
@@ -621,10 +621,37 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t quota = min(64u, (n + n_waves - 1) / n_waves);
     for (;;) {
-        // (1) idle lanes fetch a ray
-        if (state == IDLE && !exhausted && lane < quota) {
-            const uint32_t i = atomicAdd(head, 1u);
-            if (i < n) {
+        // (1) idle lanes fetch a ray.  The wave reserves queue entries a chunk at a time -- one atomic on the
+        // shared cursor per chunk, not per lane: the cursor is served one atomic at a time for the whole
+        // chip.  Chunks shrink towards the end of the queue so that the last rays spread over the waves.
+        const bool want = state == IDLE && lane < quota && !(drained && range_next >= range_end);
+        const unsigned long long fm = __ballot(want);
+        if (fm) {
+            const uint32_t cnt = static_cast<uint32_t>(__popcll(fm));
+            const uint32_t r = lanes_below(fm);
+            const uint32_t avail = range_end - range_next;
+            uint32_t i = range_next + r;
+            bool have = want && r < avail;
+            if (avail >= cnt || drained) {
+                range_next += min(cnt, avail);
+            } else {
+                const uint32_t need = cnt - avail;
+                const uint32_t left = n > seen ? n - seen : 0u;
+                const uint32_t chunk = max(need, min(256u, left / (2u * n_waves)));
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(head, chunk);
+                base = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
+                seen = base + chunk;
+                const uint32_t end = min(base + chunk, max(n, base));
+                if (base + chunk >= n) drained = true;
+                if (want && r >= avail) {
+                    i = base + (r - avail);
+                    have = i < end;
+                }
+                range_next = min(base + need, end);
+                range_end = end;
+            }
+            if (have) {
                 slot = pb.sdf_queue[i];
                 o = ld3(pb.ray_o[slot]);
                 d = ld3(pb.ray_d[slot]);
@@ -642,8 +669,6 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
                 improved = false;
                 k = 0;
                 state = SETUP;
-            } else {
-                exhausted = true;
             }
         }
         // (2) set up the march on the next SDF primitive whose box the ray reaches
@@ -681,7 +706,7 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
             ++k;
         }
         // leave only when no lane holds a ray and no lane may fetch another one
-        if (__all(state == IDLE && (exhausted || lane >= quota))) break;
+        if (__all(state == IDLE) && drained && range_next >= range_end) break;
         // (3) far-field steps are a handful of flops: take them until a near-field evaluation is due
         int result = 0;
         float s = 0.0f;
@@ -725,19 +750,8 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
 // =============================================================================================
 // shade: Scene::trace's per-hit body (src/Scene.cpp:46-75) around Object::deflectRay
 // (src/Object.cpp:35-44) and BasicMaterial::deflect.  Survivors are appended to the next bounce's
-// queue with one atomic per wave (ballot + popcount prefix).
+// queue through the wave's pending buffer.
 // =============================================================================================
-__device__ __forceinline__ void wave_append(bool pred, uint32_t value, uint32_t* counter, uint32_t* queue) {
-    const unsigned long long m = __ballot(pred);
-    if (!pred) return;
-    const uint32_t lane = __lane_id();
-    const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
-    uint32_t base = 0;
-    if (rank == 0) base = atomicAdd(counter, static_cast<uint32_t>(__popcll(m)));
-    base = __shfl(base, __ffsll(static_cast<long long>(m)) - 1);
-    queue[base + rank] = value;
-}
-
 // Applies one bounce to the path in `slot`; returns whether the path continues.
 __device__ __forceinline__ bool apply_bounce(const PathBuffers& pb, uint32_t slot, const PrimRegs& pr, f3 world_pos, const Bounce& b,
                                              uint32_t bounce, uint32_t max_bounces) {
@@ -763,6 +777,9 @@ __device__ __forceinline__ bool apply_bounce(const PathBuffers& pb, uint32_t slo
 }
 
 __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce, uint32_t max_bounces) {
+    constexpr uint32_t kCap = 1024;
+    __shared__ uint32_t s_pend[2 * 4 * kCap];
+    PendingQueue survivors{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u}, sdf_hits{s_pend + (4u + (threadIdx.x >> 6)) * kCap, kCap, 0u};
     const uint32_t n = pb.counters[bounce].n_live;
     const uint32_t* queue = pb.queue[bounce & 1];
     uint32_t* next_queue = pb.queue[(bounce + 1) & 1];
@@ -804,9 +821,11 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
                 }
             }
         }
-        wave_append(alive, slot, &pb.counters[bounce + 1].n_live, next_queue);
-        wave_append(to_sdf, slot, &pb.counters[bounce].n_sdf_shade, pb.sdf_shade_queue);
+        pending_push(survivors, alive, slot, &pb.counters[bounce + 1].n_live, next_queue);
+        pending_push(sdf_hits, to_sdf, slot, &pb.counters[bounce].n_sdf_shade, pb.sdf_shade_queue);
     }
+    pending_flush(survivors, &pb.counters[bounce + 1].n_live, next_queue);
+    pending_flush(sdf_hits, &pb.counters[bounce].n_sdf_shade, pb.sdf_shade_queue);
 }
 
 // SDF hits: the normal is a forward difference of four SDF evaluations (signedDistanceNormal,
@@ -821,6 +840,9 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
     const uint32_t rounds = (n + per_round - 1) / per_round;
     uint32_t c_evals = 0, c_near = 0, c_noise = 0;
     __shared__ __attribute__((aligned(16))) float s_near[4 * kNearLdsFloats];
+    constexpr uint32_t kCap = 256;
+    __shared__ uint32_t s_pend[4 * kCap];
+    PendingQueue survivors{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u};
     const uint32_t lane = __lane_id();
     float* lds = s_near + (threadIdx.x >> 6) * kNearLdsFloats;
     const CoopLane cl = make_coop_lane(sc.noise_oct, lane);
@@ -863,8 +885,9 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
             const Bounce b = deflect(sc.materials[pr.material], ld, nrm, rng);
             alive = apply_bounce(pb, slot, pr, wp, b, bounce, max_bounces);
         }
-        wave_append(alive, slot, &pb.counters[bounce + 1].n_live, next_queue);
+        pending_push(survivors, alive, slot, &pb.counters[bounce + 1].n_live, next_queue);
     }
+    pending_flush(survivors, &pb.counters[bounce + 1].n_live, next_queue);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.totals->sdf_shades, static_cast<unsigned long long>(n));
     if (rounds) {
         wave_add_total(&pb.totals->shade_near_evals, c_evals);
@@ -1023,7 +1046,7 @@ void launch_generate_extend(hipStream_t st, const CameraRec& cam, const SceneDev
     if (bvh_depth <= 8) hipLaunchKernelGGL(k_generate_extend<8>, grid, block, 0, st, cam, sc, bp, pb);
     else if (bvh_depth <= 24) hipLaunchKernelGGL(k_generate_extend<24>, grid, block, 0, st, cam, sc, bp, pb);
     else if (bvh_depth <= 40) hipLaunchKernelGGL(k_generate_extend<40>, grid, block, 0, st, cam, sc, bp, pb);
-    else hipLaunchKernelGGL(k_generate_extend<64>, grid, block, 0, st, cam, sc, bp, pb);
+    else hipLaunchKernelGGL(k_generate_extend<60>, grid, block, 0, st, cam, sc, bp, pb);
 }
 
 void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, int bvh_depth) {
@@ -1031,7 +1054,7 @@ void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, co
     if (bvh_depth <= 8) hipLaunchKernelGGL(k_extend<8>, grid, block, 0, st, sc, bp, pb, bounce);
     else if (bvh_depth <= 24) hipLaunchKernelGGL(k_extend<24>, grid, block, 0, st, sc, bp, pb, bounce);
     else if (bvh_depth <= 40) hipLaunchKernelGGL(k_extend<40>, grid, block, 0, st, sc, bp, pb, bounce);
-    else hipLaunchKernelGGL(k_extend<64>, grid, block, 0, st, sc, bp, pb, bounce);
+    else hipLaunchKernelGGL(k_extend<60>, grid, block, 0, st, sc, bp, pb, bounce);
 }
 
 void launch_crater_cells(hipStream_t st, const float off[3], const int base[3], int n, float* out) {
