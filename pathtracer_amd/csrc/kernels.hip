@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
     const uint32_t rounds = (n + per_round - 1) / per_round;
     uint32_t c_evals = 0, c_near = 0, c_noise = 0;
     __shared__ __attribute__((aligned(16))) float s_near[4 * kNearLdsFloats];
-    constexpr uint32_t kCap = 256;
+    constexpr uint32_t kCap = 128;   // small: three blocks of this kernel must fit the CU's LDS
     __shared__ uint32_t s_pend[4 * kCap];
     PendingQueue survivors{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u};
     const uint32_t lane = __lane_id();
