@@ -72,6 +72,8 @@ struct BounceCounters {
     uint32_t n_sdf;         // rays queued for the SDF march
     uint32_t sdf_head;      // work-fetch cursor of the SDF march
     uint32_t n_sdf_shade;   // hits queued for SDF shading
+    uint32_t extend_head[8];   // work-fetch cursors of extend, one per XCD
+    uint32_t pad[4];
 };
 
 struct Totals {

@@ -320,74 +320,141 @@ __device__ __forceinline__ void camera_ray(const CameraRec& cam, const BatchPara
 
 // =============================================================================================
 // Closest hit over the analytic primitives: ObjectTree::Tree::hit (src/ObjectTree.cpp:22-88) with real
-// culling.  The traversal stack is a column of LDS dwords per lane (entry e of lane l at
-// e * blockDim + l: conflict-free for ds_read/write_b32).  Hits are ranked by t = (hit - o).d as the
-// reference ranks them; boxes are culled in ray-parameter units, t / |d|^2, with a relative and an
-// absolute margin.  Returns the cull limit for the SDF box tests that follow.
+// culling, as a per-lane state machine that a wave steps in two phases:
+//   * inner step -- visit one BVH2 node: slab-test both children against the current limit, nearer first;
+//     children that are leaves become the lane's pending leaves, of the others one is visited next and
+//     one goes on the lane's stack (a column of LDS dwords: entry e of lane l at e * 256 + l,
+//     conflict-free);
+//   * leaf step -- Object::hitRay on the pending leaves.  A wave runs it when enough lanes have leaves
+//     pending (or none can do anything else), so the long exact intersection code runs with most lanes
+//     active instead of once per lane that happens to reach a leaf.
+// A lane whose ray is finished takes the next ray at once (the kernels below refill idle lanes), so a
+// wave is not held up by its longest ray.  Hits are ranked by t = (hit - o).d as the reference ranks
+// them; boxes are culled in ray-parameter units, t / |d|^2, with a relative and an absolute margin.
 // =============================================================================================
-// (ra..re are the four float4 of node 0, which a kernel loads once for all its rays.)
-__device__ __forceinline__ float closest_analytic(const SceneDev& sc, float4 ra, float4 rb, float4 rc, float4 re, int* stack, f3 o, f3 d, f3 inv_d,
-                                                  unsigned long long& best, f3& best_pos) {
-    const float inv_len2 = 1.0f / norm_sq(d);
-    float limit = 3.0e38f;
-    best = kMissKey;
-    best_pos = mk3(0.0f, 0.0f, 0.0f);
-    if (!sc.nodes) return limit;
-    int sp = 0;
-    float4 a = ra, b = rb, c = rc, e = re;
-    for (;;) {
-        const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y};
-        const float lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
-        int c0 = __float_as_int(e.x), c1 = __float_as_int(e.y);
-        float t0, t1;
-        bool h0 = slab(o, inv_d, lo0, hi0, limit, t0);
-        bool h1 = slab(o, inv_d, lo1, hi1, limit, t1);
-        if (h0 && h1 && t1 < t0) {   // nearer child first
-            const int tc = c0; c0 = c1; c1 = tc;
-            const float tt = t0; t0 = t1; t1 = tt;
-        } else if (!h0 && h1) {
-            c0 = c1; t0 = t1; h0 = true; h1 = false;
-        }
-        int next = -1;
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const bool h = side == 0 ? h0 : h1;
-            const int ch = side == 0 ? c0 : c1;
-            const float tn = side == 0 ? t0 : t1;
-            if (!h || tn > limit) continue;
-            if (ch < 0) {
-                const uint32_t prim = static_cast<uint32_t>(~ch);
-                PrimRegs pr;
-                load_prim(sc.prims, prim, pr);
-                f3 w;
-                float t;
-                if (hit_analytic(pr, sc.tri_c, prim, o, d, w, t)) {
-                    const unsigned long long key = make_key(t, prim);
-                    if (key < best) {
-                        best = key;
-                        best_pos = w;
-                        limit = fmaxf(t, 0.0f) * inv_len2 * 1.00001f + 1e-6f;
-                    }
-                }
-            } else if (next < 0) {
-                next = ch;
-            } else {
-                stack[sp * 256] = ch;
-                ++sp;
-            }
-        }
-        if (next < 0) {
-            if (sp == 0) break;
-            --sp;
-            next = stack[sp * 256];
-        }
-        const float4* np = reinterpret_cast<const float4*>(sc.nodes + next);
-        a = np[0];
-        b = np[1];
-        c = np[2];
-        e = np[3];
+struct Trav {
+    f3 o, d, inv_d;
+    float inv_len2, limit, tn_cur, tn_leaf1;
+    unsigned long long best;
+    f3 best_pos;
+    int cur;            // >= 0: node to visit (once no leaf is pending); kTravNone: nothing chosen yet
+    int leaf0, leaf1;   // pending leaves (primitive indices) or kTravNone; leaf1 is the farther one
+    int sp;
+    uint32_t slot;
+    bool busy;          // holds a ray
+};
+constexpr int kTravNone = -1;
+
+__device__ __forceinline__ void trav_begin(Trav& t, f3 o, f3 d, uint32_t slot, bool has_nodes) {
+    t.o = o;
+    t.d = d;
+    t.inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    t.inv_len2 = 1.0f / norm_sq(d);
+    t.limit = 3.0e38f;
+    t.tn_cur = 0.0f;
+    t.best = kMissKey;
+    t.best_pos = mk3(0.0f, 0.0f, 0.0f);
+    t.cur = has_nodes ? 0 : kTravNone;
+    t.leaf0 = t.leaf1 = kTravNone;
+    t.sp = 0;
+    t.slot = slot;
+    t.busy = true;
+}
+__device__ __forceinline__ bool trav_wants_inner(const Trav& t) { return t.busy && t.cur >= 0 && t.leaf0 == kTravNone; }
+__device__ __forceinline__ bool trav_wants_leaf(const Trav& t) { return t.busy && t.leaf0 != kTravNone; }
+__device__ __forceinline__ bool trav_finished(const Trav& t) { return t.busy && t.cur == kTravNone && t.leaf0 == kTravNone; }
+
+// After a visit or a leaf step: drop a chosen node that the limit has overtaken, then take the next one
+// from the stack if nothing is chosen.
+__device__ __forceinline__ void trav_advance(Trav& t, const int* stack) {
+    if (t.cur >= 0 && t.tn_cur > t.limit) t.cur = kTravNone;
+    if (t.cur == kTravNone && t.sp > 0) {
+        --t.sp;
+        t.cur = stack[t.sp * 256];
+        t.tn_cur = 0.0f;   // its box is tested against the limit when it is visited
     }
-    return limit;
+}
+
+__device__ __forceinline__ void trav_inner_step(const SceneDev& sc, Trav& t, int* stack) {
+    const float4* np = reinterpret_cast<const float4*>(sc.nodes + t.cur);
+    const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+    const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y};
+    const float lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
+    int c0 = __float_as_int(e.x), c1 = __float_as_int(e.y);
+    float t0, t1;
+    bool h0 = slab(t.o, t.inv_d, lo0, hi0, t.limit, t0);
+    bool h1 = slab(t.o, t.inv_d, lo1, hi1, t.limit, t1);
+    if (h0 && h1 && t1 < t0) {   // nearer child first
+        const int tc = c0; c0 = c1; c1 = tc;
+        const float tt = t0; t0 = t1; t1 = tt;
+    } else if (!h0 && h1) {
+        c0 = c1; t0 = t1; h0 = true; h1 = false;
+    }
+    t.cur = kTravNone;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const bool h = side == 0 ? h0 : h1;
+        const int ch = side == 0 ? c0 : c1;
+        const float tn = side == 0 ? t0 : t1;
+        if (!h) continue;
+        if (ch < 0) {   // leaf ~ch
+            if (t.leaf0 == kTravNone) {
+                t.leaf0 = ~ch;
+            } else {
+                t.leaf1 = ~ch;
+                t.tn_leaf1 = tn;
+            }
+        } else if (t.cur == kTravNone) {
+            t.cur = ch;
+            t.tn_cur = tn;
+        } else {
+            stack[t.sp * 256] = ch;
+            ++t.sp;
+        }
+    }
+    if (t.leaf0 == kTravNone) trav_advance(t, stack);
+}
+
+__device__ __forceinline__ void trav_test_leaf(const SceneDev& sc, Trav& t, uint32_t prim) {
+    PrimRegs pr;
+    load_prim(sc.prims, prim, pr);
+    f3 w;
+    float th;
+    if (hit_analytic(pr, sc.tri_c, prim, t.o, t.d, w, th)) {
+        const unsigned long long key = make_key(th, prim);
+        if (key < t.best) {
+            t.best = key;
+            t.best_pos = w;
+            t.limit = fmaxf(th, 0.0f) * t.inv_len2 * 1.00001f + 1e-6f;
+        }
+    }
+}
+
+// One pending leaf per call (the nearer first; the farther one only if the limit still reaches its box).
+__device__ __forceinline__ void trav_leaf_step(const SceneDev& sc, Trav& t, const int* stack) {
+    trav_test_leaf(sc, t, static_cast<uint32_t>(t.leaf0));
+    t.leaf0 = kTravNone;
+    if (t.leaf1 != kTravNone) {
+        if (!(t.tn_leaf1 > t.limit)) t.leaf0 = t.leaf1;
+        t.leaf1 = kTravNone;
+    }
+    if (t.leaf0 == kTravNone) trav_advance(t, stack);
+}
+
+// Steps the wave's rays until fewer than `keep_busy` lanes hold an unfinished ray (so the caller can
+// refill) -- or, with keep_busy = 0, until all are finished.  Always takes at least one step.  All 64
+// lanes call.
+__device__ __forceinline__ void trav_run(const SceneDev& sc, Trav& t, int* stack, uint32_t keep_busy) {
+    constexpr uint32_t kLeafQuorum = 20;   // lanes with a pending leaf that make a leaf step worth its cost
+    for (;;) {
+        if (trav_wants_inner(t)) trav_inner_step(sc, t, stack);
+        const uint32_t n_leaf = static_cast<uint32_t>(__popcll(__ballot(trav_wants_leaf(t))));
+        if (n_leaf >= kLeafQuorum || (n_leaf > 0 && !__ballot(trav_wants_inner(t)))) {
+            if (trav_wants_leaf(t)) trav_leaf_step(sc, t, stack);
+        }
+        const uint32_t n_unfinished = static_cast<uint32_t>(__popcll(__ballot(t.busy && !trav_finished(t))));
+        if (n_unfinished == 0 || n_unfinished < keep_busy) return;
+    }
 }
 
 // Does the ray reach any SDF primitive's box before its best analytic hit?
@@ -438,63 +505,136 @@ __device__ __forceinline__ void pending_push(PendingQueue& q, bool pred, uint32_
     q.count += static_cast<uint32_t>(__popcll(m));
 }
 
+// A wave's share of a work queue: entries are reserved a chunk at a time, one atomic on the shared
+// cursor per chunk (the cursor is served one atomic at a time for the whole chip); chunks shrink towards
+// the end of the queue so that the last entries spread over the waves.
+struct QueueCursor {
+    uint32_t next, end, seen;   // wave-uniform: reserved range, cursor position as last seen
+    bool drained;               // the queue has been handed out completely
+};
+__device__ __forceinline__ bool cursor_empty(const QueueCursor& q) { return q.drained && q.next >= q.end; }
+// All 64 lanes call; lanes with `want` get an entry index in `i` (returns whether they did).
+__device__ __forceinline__ bool cursor_take(QueueCursor& q, bool want, uint32_t* head, uint32_t n, uint32_t n_waves, uint32_t max_chunk, uint32_t& i) {
+    const unsigned long long fm = __ballot(want);
+    if (!fm) return false;
+    const uint32_t cnt = static_cast<uint32_t>(__popcll(fm));
+    const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(fm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(fm), 0u));
+    const uint32_t avail = q.end - q.next;
+    i = q.next + r;
+    bool have = want && r < avail;
+    if (avail >= cnt || q.drained) {
+        q.next += min(cnt, avail);
+    } else {
+        const uint32_t need = cnt - avail;
+        const uint32_t left = n > q.seen ? n - q.seen : 0u;
+        const uint32_t chunk = max(need, min(max_chunk, left / (2u * n_waves)));
+        uint32_t base = 0;
+        if (__lane_id() == 0) base = atomicAdd(head, chunk);
+        base = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
+        q.seen = base + chunk;
+        const uint32_t end = min(base + chunk, max(n, base));
+        if (base + chunk >= n) q.drained = true;
+        if (want && r >= avail) {
+            i = base + (r - avail);
+            have = i < end;
+        }
+        q.next = min(base + need, end);
+        q.end = end;
+    }
+    return have;
+}
+
+// The same for a queue whose consumer is followed by a grid-stride kernel over the same entries (extend,
+// then shade): entries are handed out in blocks of 256, block c to the waves of XCD c mod 8 (workgroups
+// go to the XCDs round-robin, so that is where the follow-up kernel's workgroup c runs too), and what
+// this kernel writes for those entries is still in that XCD's L2 when the follow-up reads it.  Each XCD
+// has its own cursor; a wave whose XCD has run out helps the next one.  Placement is an optimisation
+// only: any wave may process any entry.
+struct XcdCursor {
+    uint32_t next, end;   // wave-uniform: reserved range
+    uint32_t xcd, tried;  // cursor in use, number of cursors found exhausted
+};
+__device__ __forceinline__ bool xcd_cursor_empty(const XcdCursor& q) { return q.tried >= 8u && q.next >= q.end; }
+__device__ __forceinline__ bool xcd_cursor_take(XcdCursor& q, bool want, uint32_t* heads, uint32_t n, uint32_t& i) {
+    const unsigned long long fm = __ballot(want);
+    if (!fm) return false;
+    const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(fm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(fm), 0u));
+    while (q.next >= q.end && q.tried < 8u) {
+        uint32_t c = 0;
+        if (__lane_id() == 0) c = atomicAdd(&heads[q.xcd], 1u);
+        c = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(c)));
+        const unsigned long long begin = (static_cast<unsigned long long>(c) * 8u + q.xcd) * 256u;
+        if (begin < n) {
+            q.next = static_cast<uint32_t>(begin);
+            q.end = min(q.next + 256u, n);
+        } else {
+            q.xcd = (q.xcd + 1u) & 7u;
+            ++q.tried;
+        }
+    }
+    i = q.next + r;
+    const bool have = want && i < q.end;
+    q.next = min(q.next + static_cast<uint32_t>(__popcll(fm)), q.end);
+    return have;
+}
+
 // =============================================================================================
 // generate + first extend, fused: a primary ray lives in registers from the camera to its closest hit.
-// Only paths that hit an analytic primitive or reach an SDF box are written to HBM (ray, hit) and
-// queued for the stages that follow; on the demo scene that is ~10 % of the paths, the rest cost no
-// memory traffic at all.
+// A lane owns one pixel and walks a stripe of its samples (blockIdx.y, blockIdx.y + gridDim.y, ...).
+// Only paths that hit an analytic primitive or
+// reach an SDF box are written to HBM (ray, hit) and queued for the stages that follow; on the demo
+// scene that is ~10 % of the paths, the rest cost no memory traffic at all.
 // =============================================================================================
-template <int STACK>
+template <int STACK, int CAP>
 __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev sc, BatchParams bp, PathBuffers pb) {
     __shared__ int s_stack[STACK * 256];
-    constexpr uint32_t kCap = 1024;
-    __shared__ uint32_t s_pend[2 * 4 * kCap];
+    __shared__ uint32_t s_pend[2 * 4 * CAP];
     int* stack = s_stack + threadIdx.x;
-    PendingQueue live{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u}, to_sdf{s_pend + (4u + (threadIdx.x >> 6)) * kCap, kCap, 0u};
-    // a thread owns one pixel and walks a stripe of its samples: blockIdx.y, blockIdx.y + gridDim.y, ...
-    // (threads past the image run along with no work so that the wave-wide steps stay aligned)
-    const uint32_t pix_raw = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_image = pix_raw < bp.n_pix;
-    const uint32_t pix = in_image ? pix_raw : bp.n_pix - 1u;
+    PendingQueue live{s_pend + (threadIdx.x >> 6) * CAP, CAP, 0u}, to_sdf{s_pend + (4u + (threadIdx.x >> 6)) * CAP, CAP, 0u};
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_image = pix < bp.n_pix;
     const uint32_t samples = bp.n_slots / bp.n_pix;
     const uint32_t y = pix / bp.width, x = pix - y * bp.width;
     const float sx0 = static_cast<float>(x) / static_cast<float>(bp.width - 1);
     const float sy0 = static_cast<float>(y) / static_cast<float>(bp.height - 1);
-    float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra, re = ra;
-    if (sc.nodes) {
-        const float4* np = reinterpret_cast<const float4*>(sc.nodes);
-        ra = np[0];
-        rb = np[1];
-        rc = np[2];
-        re = np[3];
-    }
     f3 box_lo = mk3(0, 0, 0), box_hi = mk3(0, 0, 0);
     if (sc.n_sdf) {
         box_lo = mk3(sc.sdf_boxes[0].lo[0], sc.sdf_boxes[0].lo[1], sc.sdf_boxes[0].lo[2]);
         box_hi = mk3(sc.sdf_boxes[0].hi[0], sc.sdf_boxes[0].hi[1], sc.sdf_boxes[0].hi[2]);
     }
     uint32_t n_sdf_rays = 0;
-    for (uint32_t s_local = blockIdx.y; s_local < samples; s_local += gridDim.y) {
-        const uint32_t slot = s_local * bp.n_pix + pix;
-        bool keep = false, wants_sdf = false;
-        if (in_image) {
+    uint32_t s_next = in_image ? blockIdx.y : samples;   // this lane's next sample
+    Trav t;
+    t.busy = false;
+    for (;;) {
+        // refill: idle lanes start their next sample
+        if (!t.busy && s_next < samples) {
             f3 o, d;
-            camera_ray(cam, bp, pix, bp.first_sample + s_local, sx0, sy0, o, d);
-            const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-            unsigned long long best;
-            f3 best_pos;
-            const float limit = closest_analytic(sc, ra, rb, rc, re, stack, o, d, inv_d, best, best_pos);
-            wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, o, inv_d, limit);
-            keep = best != kMissKey || wants_sdf;
-            if (keep) {
-                pb.ray_o[slot] = st4(o);
-                pb.ray_d[slot] = st4(d);
-                pb.hit_key[slot] = best;
-                pb.hit_pos[slot] = st4(best_pos);
-            }
+            camera_ray(cam, bp, pix, bp.first_sample + s_next, sx0, sy0, o, d);
+            trav_begin(t, o, d, s_next * bp.n_pix + pix, sc.nodes != nullptr);
+            s_next += gridDim.y;
         }
-        pending_push(live, keep, slot, &pb.counters[0].n_live, pb.queue[0]);
-        pending_push(to_sdf, wants_sdf, slot, &pb.counters[0].n_sdf, pb.sdf_queue);
+        if (!__ballot(t.busy)) break;
+        // The wave's 64 rays of one sample run to the end together: neighbouring pixels take about equally
+        // long, and their queue entries then name 64 consecutive slots, which is what lets the kernels that
+        // read the queue later fetch the paths' state in full cache lines.
+        trav_run(sc, t, stack, 0u);
+        // finished rays: keep what hit something or reaches an SDF box
+        const bool fin = trav_finished(t);
+        bool keep = false, wants_sdf = false;
+        if (fin) {
+            wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, t.o, t.inv_d, t.limit);
+            keep = t.best != kMissKey || wants_sdf;
+            if (keep) {
+                pb.ray_o[t.slot] = st4(t.o);
+                pb.ray_d[t.slot] = st4(t.d);
+                pb.hit_key[t.slot] = t.best;
+                pb.hit_pos[t.slot] = st4(t.best_pos);
+            }
+            t.busy = false;
+        }
+        pending_push(live, keep, t.slot, &pb.counters[0].n_live, pb.queue[0]);
+        pending_push(to_sdf, wants_sdf, t.slot, &pb.counters[0].n_sdf, pb.sdf_queue);
         n_sdf_rays += wants_sdf ? 1u : 0u;
     }
     pending_flush(live, &pb.counters[0].n_live, pb.queue[0]);
@@ -504,7 +644,7 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
 
 // =============================================================================================
 // extend: closest hit for the rays of the live-path queue (bounces after the first, or rays loaded
-// from the host).  One lane per ray.
+// from the host).  Persistent waves; a lane that finishes its ray takes the next one from the queue.
 // =============================================================================================
 template <int STACK>
 __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
@@ -513,42 +653,41 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
     __shared__ uint32_t s_pend[4 * kCap];
     PendingQueue to_sdf{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u};
     const uint32_t n = pb.counters[bounce].n_live;
+    if (n == 0) return;
     const uint32_t* queue = pb.queue[bounce & 1];
-    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t* heads = pb.counters[bounce].extend_head;
     int* stack = s_stack + threadIdx.x;
-    float4 ra = make_float4(0, 0, 0, 0), rb = ra, rc = ra, re = ra;
-    if (sc.nodes) {
-        const float4* np = reinterpret_cast<const float4*>(sc.nodes);
-        ra = np[0];
-        rb = np[1];
-        rc = np[2];
-        re = np[3];
-    }
     f3 box_lo = mk3(0, 0, 0), box_hi = mk3(0, 0, 0);
     if (sc.n_sdf) {
         box_lo = mk3(sc.sdf_boxes[0].lo[0], sc.sdf_boxes[0].lo[1], sc.sdf_boxes[0].lo[2]);
         box_hi = mk3(sc.sdf_boxes[0].hi[0], sc.sdf_boxes[0].hi[1], sc.sdf_boxes[0].hi[2]);
     }
     uint32_t n_sdf_rays = 0;
-    // all lanes of a wave run the same number of rounds so that the wave-wide steps line up
-    const uint32_t rounds = (n + stride - 1) / stride;
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        bool wants_sdf = false;
-        uint32_t slot = 0;
-        if (i < n) {
-            slot = queue[i];
-            const f3 o = ld3(pb.ray_o[slot]);
-            const f3 d = ld3(pb.ray_d[slot]);
-            const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-            unsigned long long best;
-            f3 best_pos;
-            const float limit = closest_analytic(sc, ra, rb, rc, re, stack, o, d, inv_d, best, best_pos);
-            pb.hit_key[slot] = best;
-            pb.hit_pos[slot] = st4(best_pos);
-            wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, o, inv_d, limit);
+    XcdCursor cursor{0u, 0u, blockIdx.x & 7u, 0u};
+    Trav t;
+    t.busy = false;
+    for (;;) {
+        // refill idle lanes from the queue
+        uint32_t i = 0;
+        if (xcd_cursor_take(cursor, !t.busy && !xcd_cursor_empty(cursor), heads, n, i)) {
+            const uint32_t slot = queue[i];
+            trav_begin(t, ld3(pb.ray_o[slot]), ld3(pb.ray_d[slot]), slot, sc.nodes != nullptr);
         }
-        pending_push(to_sdf, wants_sdf, slot, &pb.counters[bounce].n_sdf, pb.sdf_queue);
+        if (!__ballot(t.busy)) {
+            if (xcd_cursor_empty(cursor)) break;
+            continue;
+        }
+        const uint32_t n_busy = static_cast<uint32_t>(__popcll(__ballot(t.busy)));
+        trav_run(sc, t, stack, xcd_cursor_empty(cursor) ? 0u : (3u * n_busy) / 4u);
+        const bool fin = trav_finished(t);
+        bool wants_sdf = false;
+        if (fin) {
+            pb.hit_key[t.slot] = t.best;
+            pb.hit_pos[t.slot] = st4(t.best_pos);
+            wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, t.o, t.inv_d, t.limit);
+            t.busy = false;
+        }
+        pending_push(to_sdf, wants_sdf, t.slot, &pb.counters[bounce].n_sdf, pb.sdf_queue);
         n_sdf_rays += wants_sdf ? 1u : 0u;
     }
     pending_flush(to_sdf, &pb.counters[bounce].n_sdf, pb.sdf_queue);
@@ -598,8 +737,7 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
     uint32_t* head = &pb.counters[bounce].sdf_head;
     constexpr int IDLE = 0, SETUP = 1, MARCH = 2;
     int state = IDLE;
-    uint32_t range_next = 0, range_end = 0, seen = 0;   // this wave's reserved queue entries; the cursor as last seen
-    bool drained = false;                               // the queue has been handed out completely
+    QueueCursor cursor{0u, 0u, 0u, false};
     uint32_t slot = 0, k = 0, prim = 0, crater_base = 0, crater_count = 0;
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv_d = mk3(0, 0, 0), off = mk3(0, 0, 0), best_pos = mk3(0, 0, 0);
     float inv_len2 = 0.0f, limit = 0.0f;
@@ -624,33 +762,9 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
         // (1) idle lanes fetch a ray.  The wave reserves queue entries a chunk at a time -- one atomic on the
         // shared cursor per chunk, not per lane: the cursor is served one atomic at a time for the whole
         // chip.  Chunks shrink towards the end of the queue so that the last rays spread over the waves.
-        const bool want = state == IDLE && lane < quota && !(drained && range_next >= range_end);
-        const unsigned long long fm = __ballot(want);
-        if (fm) {
-            const uint32_t cnt = static_cast<uint32_t>(__popcll(fm));
-            const uint32_t r = lanes_below(fm);
-            const uint32_t avail = range_end - range_next;
-            uint32_t i = range_next + r;
-            bool have = want && r < avail;
-            if (avail >= cnt || drained) {
-                range_next += min(cnt, avail);
-            } else {
-                const uint32_t need = cnt - avail;
-                const uint32_t left = n > seen ? n - seen : 0u;
-                const uint32_t chunk = max(need, min(256u, left / (2u * n_waves)));
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(head, chunk);
-                base = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
-                seen = base + chunk;
-                const uint32_t end = min(base + chunk, max(n, base));
-                if (base + chunk >= n) drained = true;
-                if (want && r >= avail) {
-                    i = base + (r - avail);
-                    have = i < end;
-                }
-                range_next = min(base + need, end);
-                range_end = end;
-            }
+        uint32_t i = 0;
+        const bool have = cursor_take(cursor, state == IDLE && lane < quota && !cursor_empty(cursor), head, n, n_waves, 256u, i);
+        {
             if (have) {
                 slot = pb.sdf_queue[i];
                 o = ld3(pb.ray_o[slot]);
@@ -706,7 +820,7 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
             ++k;
         }
         // leave only when no lane holds a ray and no lane may fetch another one
-        if (__all(state == IDLE) && drained && range_next >= range_end) break;
+        if (__all(state == IDLE) && cursor_empty(cursor)) break;
         // (3) far-field steps are a handful of flops: take them until a near-field evaluation is due
         int result = 0;
         float s = 0.0f;
@@ -1043,14 +1157,16 @@ void launch_generate_extend(hipStream_t st, const CameraRec& cam, const SceneDev
     const uint32_t bx = (bp.n_pix + 255u) / 256u, samples = bp.n_slots / bp.n_pix;
     const uint32_t by = std::max(1u, std::min(samples, (4096u + bx - 1u) / bx));
     const dim3 grid(bx, by), block(256);
-    if (bvh_depth <= 8) hipLaunchKernelGGL(k_generate_extend<8>, grid, block, 0, st, cam, sc, bp, pb);
-    else if (bvh_depth <= 24) hipLaunchKernelGGL(k_generate_extend<24>, grid, block, 0, st, cam, sc, bp, pb);
-    else if (bvh_depth <= 40) hipLaunchKernelGGL(k_generate_extend<40>, grid, block, 0, st, cam, sc, bp, pb);
-    else hipLaunchKernelGGL(k_generate_extend<60>, grid, block, 0, st, cam, sc, bp, pb);
+    // (traversal stack, pending-queue capacity): LDS per block = STACK KiB + 8 CAP bytes, at most 64 KiB
+    if (bvh_depth <= 8) hipLaunchKernelGGL((k_generate_extend<8, 1024>), grid, block, 0, st, cam, sc, bp, pb);
+    else if (bvh_depth <= 24) hipLaunchKernelGGL((k_generate_extend<24, 512>), grid, block, 0, st, cam, sc, bp, pb);
+    else if (bvh_depth <= 40) hipLaunchKernelGGL((k_generate_extend<40, 256>), grid, block, 0, st, cam, sc, bp, pb);
+    else hipLaunchKernelGGL((k_generate_extend<60, 128>), grid, block, 0, st, cam, sc, bp, pb);
 }
 
 void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, int bvh_depth) {
-    const dim3 grid(grid_for(bp.n_slots, 256u * 16u)), block(256);
+    // persistent waves: every wave drains the queue
+    const dim3 grid(256u * 4u), block(256);
     if (bvh_depth <= 8) hipLaunchKernelGGL(k_extend<8>, grid, block, 0, st, sc, bp, pb, bounce);
     else if (bvh_depth <= 24) hipLaunchKernelGGL(k_extend<24>, grid, block, 0, st, sc, bp, pb, bounce);
     else if (bvh_depth <= 40) hipLaunchKernelGGL(k_extend<40>, grid, block, 0, st, sc, bp, pb, bounce);
