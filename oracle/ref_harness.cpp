@@ -85,6 +85,11 @@ std::unique_ptr<Object> make_object(uint32_t kind, const float* p, const BasicMa
         case 1: return std::make_unique<BoxObject>(Rectangle(Vec(p[0], p[1], p[2])), m);
         case 2: return std::make_unique<TriangleObject>(Triangle(Pos(p[0], p[1], p[2]), Pos(p[3], p[4], p[5]), Pos(p[6], p[7], p[8])), m);
         case 3: return std::make_unique<CraterBallObject>(m, Vec(p[0], p[1], p[2]));
+        case 4: {
+            auto o = std::make_unique<FractalObject>();
+            o->material = m;
+            return o;
+        }
     }
     return nullptr;
 }

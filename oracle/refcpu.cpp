@@ -521,8 +521,44 @@ V3 sdf_normal(V3 pos, Sdf&& sdf) {   // signedDistanceNormal include/Object.hpp:
     return unit(div(v3(sdf(pos + v3(delta, 0, 0)) - d0, sdf(pos + v3(0, delta, 0)) - d0, sdf(pos + v3(0, 0, delta)) - d0), delta));
 }
 
-std::optional<V3> hit_local(uint32_t kind, const float* p, const Aff& noise, const Ray& r, SdfCounters* cnt) {
+// FractalObject (src/Object.cpp:160-252): a 3 x 3 x 3 lattice of spheres of radius 0.2.
+float fractal_sdf(V3 p) {   // :198-252
+    auto f = [](float v) {
+        const float l = 0.5f, r = 2.0f;
+        if (v < -l) return v + l;
+        if (v > l) return v - l;
+        v *= r;
+        return (v - std::round(v)) / r;
+    };
+    return norm(v3(f(p.x), f(p.y), f(p.z))) - 0.2f;
+}
+
+// :160-175 -- the march starts where the LOCAL ray enters the object's WORLD bounding box
+// (`intersect(ray, getBoundingBox())`), takes up to 256 steps of the signed distance and never leaves early.
+std::optional<V3> fractal_march(const Ray& r, const Box& world_box) {
+    const auto p0 = hit_aabb(r, world_box);
+    if (!p0) return std::nullopt;
+    V3 p = *p0;
+    for (int i = 0; i < 256; ++i) {
+        const float d = fractal_sdf(p);
+        if (d < 1e-3f) return p;
+        p = p + d * r.dir;
+    }
+    return std::nullopt;
+}
+
+V3 fractal_normal(V3 pos) {   // :177-189, central differences
+    const float delta = 1e-3f;
+    const V3 dx = v3(delta, 0, 0), dy = v3(0, delta, 0), dz = v3(0, 0, delta);
+    return unit(div(v3(fractal_sdf(pos + dx) - fractal_sdf(pos - dx), fractal_sdf(pos + dy) - fractal_sdf(pos - dy),
+                       fractal_sdf(pos + dz) - fractal_sdf(pos - dz)), delta));
+}
+
+Box world_bbox(uint32_t kind, const Aff& T, const float* p);
+
+std::optional<V3> hit_local(uint32_t kind, const float* p, const Aff& noise, const Aff& fwd, const Ray& r, SdfCounters* cnt) {
     switch (kind) {
+        case ORC_FRACTAL: return fractal_march(r, world_bbox(kind, fwd, p));
         case ORC_SPHERE: return hit_sphere(r, p[0]);                                   // src/Object.cpp:116-118
         case ORC_BOX: return hit_rect(r, v3(p[0], p[1], p[2]));                        // :141-143
         case ORC_TRIANGLE: return hit_triangle(r, v3(p[0], p[1], p[2]), v3(p[3], p[4], p[5]), v3(p[6], p[7], p[8]));   // :88-90
@@ -546,6 +582,7 @@ V3 normal_local(uint32_t kind, const float* p, const Aff& noise, V3 pos, SdfCoun
             const V3 off = v3(p[0], p[1], p[2]);
             return sdf_normal(pos, [&](V3 q) { return craterball_sdf(off, noise, q, cnt); });
         }
+        case ORC_FRACTAL: return fractal_normal(pos);
     }
     return v3(0, 0, 1);
 }
@@ -561,6 +598,7 @@ Box local_bbox(uint32_t kind, const float* p) {   // *::getLocalBoundingBox src/
                              std::max({p[2], p[5], p[8]}) + 1e-3f);
             return box_from_corners(lo, hi);
         }
+        case ORC_FRACTAL: return Box{v3(0, 0, 0), v3(2.0f, 2.0f, 2.0f)};   // src/Object.cpp:191-196
         default: return kCraterBox;
     }
 }
@@ -583,7 +621,7 @@ Box world_bbox(uint32_t kind, const Aff& T, const float* p) {   // Object::getBo
 // Object::hitRay src/Object.cpp:22-33 -- the local direction is not renormalised.
 std::optional<V3> hit_object(const SceneData& s, const Prim& o, const Ray& r, SdfCounters* cnt) {
     const Ray local{xform_vec(o.inv, r.dir), xform_pos(o.inv, r.pos)};
-    auto h = hit_local(o.kind, o.p, s.noise, local, cnt);
+    auto h = hit_local(o.kind, o.p, s.noise, o.fwd, local, cnt);
     if (!h) return std::nullopt;
     return xform_pos(o.fwd, *h);
 }
@@ -883,7 +921,7 @@ void orc_hit_local(uint32_t kind, const float params[9], const float noise12[12]
     const Aff nt = noise12 ? load_aff(noise12) : Aff{identity(), v3(0, 0, 0)};
     for (uint32_t i = 0; i < n; ++i) {
         const Ray r{v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), v3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2])};
-        const auto h = hit_local(kind, params, nt, r, nullptr);
+        const auto h = hit_local(kind, params, nt, Aff{identity(), v3(0, 0, 0)}, r, nullptr);   // identity transformation
         out_hit[i] = h ? 1 : 0;
         const V3 p = h ? *h : v3(0, 0, 0);
         out_pos[3 * i] = p.x;

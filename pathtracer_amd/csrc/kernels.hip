@@ -544,12 +544,11 @@ __device__ __forceinline__ bool cursor_take(QueueCursor& q, bool want, uint32_t*
     return have;
 }
 
-// The same for a queue whose consumer is followed by a grid-stride kernel over the same entries (extend,
-// then shade): entries are handed out in blocks of 256, block c to the waves of XCD c mod 8 (workgroups
-// go to the XCDs round-robin, so that is where the follow-up kernel's workgroup c runs too), and what
-// this kernel writes for those entries is still in that XCD's L2 when the follow-up reads it.  Each XCD
-// has its own cursor; a wave whose XCD has run out helps the next one.  Placement is an optimisation
-// only: any wave may process any entry.
+// The same with eight cursors instead of one: entries are handed out in blocks of 256, block c through
+// cursor c mod 8, and a workgroup starts on cursor blockIdx mod 8 (workgroups go to the XCDs round-robin,
+// so the waves of one XCD share a cursor and work on neighbouring blocks).  A wave whose cursor has run
+// out moves on to the next one.  This spreads the atomics over eight addresses; which wave processes
+// which entry never matters for the result.
 struct XcdCursor {
     uint32_t next, end;   // wave-uniform: reserved range
     uint32_t xcd, tried;  // cursor in use, number of cursors found exhausted

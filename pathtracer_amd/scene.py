@@ -14,7 +14,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-SPHERE, BOX, TRIANGLE, CRATERBALL = 0, 1, 2, 3
+SPHERE, BOX, TRIANGLE, CRATERBALL, FRACTAL = 0, 1, 2, 3, 4
 
 IDENTITY12 = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float32)
 
@@ -91,6 +91,10 @@ class SceneBuilder:
 
     def craterball(self, offset, mat, fwd=None):
         return self._add(CRATERBALL, list(offset), mat, fwd)
+
+    def fractal(self, mat, fwd=None):
+        """FractalObject (include/Object.hpp:179-192): no parameters beyond its material."""
+        return self._add(FRACTAL, [], mat, fwd)
 
     def build(self):
         fwd = np.stack(self.fwd).astype(np.float32)

@@ -85,6 +85,14 @@ def make_inputs():
     inp["sdf_ray_pos"], inp["sdf_ray_dir"] = o.astype(np.float32), dd.astype(np.float32)
     inp["crater_offset"] = np.array([-8.0, 15.0, -6.5], np.float32)
 
+    # --- FractalObject: rays towards and past the lattice of spheres, a few origins inside its box
+    r = _rs(7)
+    o = _unit(r.normal(size=(500, 3))) * r.uniform(3.6, 7.0, (500, 1))
+    tgt = r.uniform(-0.85, 0.85, (500, 3))
+    dd = (tgt - o) * r.choice([0.2, 1.0, 1.7], (500, 1))     # local directions are not unit length
+    o[:30] = r.uniform(-1.9, 1.9, (30, 3))
+    inp["fr_ray_pos"], inp["fr_ray_dir"] = o.astype(np.float32), dd.astype(np.float32)
+
     # --- camera
     g = np.linspace(0, 1, 9, dtype=np.float32)
     sx, sy = np.meshgrid(g, g)
@@ -157,6 +165,27 @@ def mixed_scene(alg):
     b.box((1.0, 0.05, 1.0), S.material(diffuse=1.0, specular=0.0, emitted=(20.0, 18.0, 15.0)), S.translation(0.0, -4.5, 0.0))
     b.sphere(0.7, S.material(diffuse=0.0, specular=0.0, transmittance=1.0, ior=2.5), S.translation(-2.5, 0.5, -0.5))
     return b.build()
+
+
+def fractal_scene(alg):
+    """A rotated, displaced FractalObject over a floor, lit by a slab.  (No scale: the object marches from
+    where its LOCAL ray enters its WORLD box, which only works while the camera lies outside that box as
+    the object's frame sees it.)"""
+    b = S.SceneBuilder(alg)
+    fr = alg.affine_mul(S.translation(0.3, -0.2, 0.5),
+                        alg.affine_mul(S.linear_to_affine(alg.rotation("y", 0.6)),
+                                       S.linear_to_affine(alg.rotation("x", -0.35))))
+    b.fractal(S.material(diffuse=0.8, specular=0.2, sharpness=0.6, albedo=(0.9, 0.6, 0.3)), fr)
+    b.box((6.0, 0.1, 6.0), S.material(diffuse=1.0, specular=0.0, albedo=(0.7, 0.7, 0.7)), S.translation(0.0, 3.2, 0.0))
+    b.box((2.0, 0.05, 2.0), S.material(diffuse=1.0, specular=0.0, emitted=(12.0, 11.0, 10.0)), S.translation(0.0, -5.0, 0.0))
+    b.sphere(0.6, S.material(diffuse=0.1, specular=0.9, sharpness=0.95), S.translation(-2.6, 2.4, -0.5))
+    return b.build()
+
+
+def fractal_camera(alg, aspect=1.0):
+    """Close enough for the lattice to fill a good part of the frame, and outside the object's world box
+    as the object's own frame sees it."""
+    return S.camera(S.translation(0.0, 0.0, -8.0), aspect=aspect, fov=12.0, focal=10.0, blur=0.0)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -352,6 +381,19 @@ def evaluate(be, inp, heavy=True):
     sc = be.scene(cb)
     out["cb_primary_prim"], out["cb_primary_t"] = sc.primary_hits(S.cornell_camera(alg), 64, 64)
     out["cb_render"] = be.render(sc, S.cornell_camera(alg), 40, 40, 8, 4, 23)
+
+    # FractalObject: local march and normals, world box, and a scene that holds one
+    fp = np.zeros(9, np.float32)
+    hit, pos = be.hit_local(4, fp, inp["fr_ray_pos"], inp["fr_ray_dir"])
+    out["fr_hit"], out["fr_hitpos"] = hit, pos
+    out["fr_normal"] = be.normal_local(4, fp, pos[hit][:128])
+    fs = fractal_scene(alg)
+    out["fr_bbox"] = api.world_bbox(4, fs.fwd[0], fp)
+    sc = be.scene(fs)
+    fcam = fractal_camera(alg)
+    out["fr_primary_prim"], out["fr_primary_t"] = sc.primary_hits(fcam, 64, 64)
+    out["fr_trace"] = be.trace(sc, o[:150] * 0.9, d[:150], 6, 7)
+    out["fr_render"] = be.render(sc, fcam, 32, 32, 6, 2, 26)
 
     if heavy:
         dm = S.demo_scene(alg, be.noise)
