@@ -485,6 +485,7 @@ private:
     std::optional<Pos> hitLocalRay(const Ray& ray) const noexcept override;
     ColorBounce deflectLocalRay(const Ray& ray) const noexcept override;
     AxisAlignedBox getLocalBoundingBox() const noexcept override;
+    void describeForDevice(mipt_host::DevicePrimitive&) const noexcept override;
     float signedDistance(const Pos&) const noexcept;
 };
 

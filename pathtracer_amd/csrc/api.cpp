@@ -395,7 +395,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     bool any_tri = false, any_sdf = false;
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t k = d->kind[i];
-        if (k > MIPT_CRATERBALL || d->material[i] >= d->n_materials) return MIPT_ERR_ARGUMENT;
+        if (k > MIPT_FRACTAL || d->material[i] >= d->n_materials) return MIPT_ERR_ARGUMENT;
         any_tri |= (k == MIPT_TRIANGLE);
         any_sdf |= (k == MIPT_CRATERBALL);
     }
@@ -412,6 +412,14 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
         if (r.kind == MIPT_TRIANGLE) std::memcpy(&tri_c[3 * static_cast<size_t>(i)], p + 6, sizeof(float) * 3);
         float lo[3], hi[3];
         if (!world_bounds(r.kind, r.fwd, p, lo, hi)) return MIPT_ERR_ARGUMENT;
+        if (r.kind == MIPT_FRACTAL) {
+            // FractalObject marches from where its LOCAL ray enters its WORLD bounding box
+            // (src/Object.cpp:161): keep that box as AxisAlignedBox(Pos, Pos) forms it (src/Geometry.cpp:348-358)
+            for (int a = 0; a < 3; ++a) {
+                r.p[a] = lo[a] + 0.5f * (hi[a] - lo[a]);
+                r.p[3 + a] = 0.5f * std::fabs(lo[a] - hi[a]);
+            }
+        }
         // The reference's hits lie inside its padded boxes (1e-3 in local units); widen a little more
         // so that rounding in the hit position or in the slab test can never cull a hit it would find.
         for (int a = 0; a < 3; ++a) {
@@ -420,7 +428,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
             lo[a] -= pad;
             hi[a] += pad;
         }
-        if (r.kind == MIPT_CRATERBALL) {
+        if (r.kind == MIPT_CRATERBALL || r.kind == MIPT_FRACTAL) {
             SdfBox s{};
             std::memcpy(s.lo, lo, sizeof(lo));
             std::memcpy(s.hi, hi, sizeof(hi));

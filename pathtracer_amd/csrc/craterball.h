@@ -235,6 +235,10 @@ __device__ __forceinline__ CoopLane make_coop_lane(const float* noise_oct, uint3
     c.si = static_cast<float>((lane >> 2) & 1u);
     c.sj = static_cast<float>((lane >> 1) & 1u);
     c.sk = static_cast<float>(lane & 1u);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.A[i] = 0.0f;
+    c.b[0] = c.b[1] = c.b[2] = c.k = 0.0f;
+    if (!noise_oct) return c;   // a scene without crater balls carries no octave table (and never evaluates one)
     const float* o = noise_oct + 13 * (lane & 7u);
 #pragma unroll
     for (int i = 0; i < 9; ++i) c.A[i] = o[i];

@@ -80,6 +80,7 @@ bool world_bounds(uint32_t kind, const float fwd[12], const float p[9], float lo
             break;
         }
         case 3: h[0] = h[1] = h[2] = 1.0f; break;
+        case 4: h[0] = h[1] = h[2] = 2.0f; break;   // FractalObject::getLocalBoundingBox src/Object.cpp:191-196
         default: return false;
     }
     for (int k = 0; k < 3; ++k) {

@@ -286,6 +286,44 @@ __device__ __forceinline__ bool slab(f3 o, f3 inv_d, const float* lo, const floa
 }
 
 // =============================================================================================
+// FractalObject (src/Object.cpp:160-252): a 3 x 3 x 3 lattice of spheres of radius 0.2 as a signed
+// distance, marched lane by lane (an evaluation is a dozen instructions).  Exact arithmetic in the
+// reference's order, so its hits are bit-identical to the reference's.
+// =============================================================================================
+__device__ __forceinline__ float fractal_axis(float v) {   // the lambda `f` :231-242
+    const float l = 0.5f, r = 2.0f;
+    if (v < -l) return v + l;
+    if (v > l) return v - l;
+    v *= r;
+    return (v - roundf(v)) / r;
+}
+__device__ __forceinline__ float fractal_sdf(f3 p) {   // :198-252
+    return norm(mk3(fractal_axis(p.x), fractal_axis(p.y), fractal_axis(p.z))) - 0.2f;
+}
+// hitLocalRay :160-175.  The march starts where the LOCAL ray enters the object's WORLD bounding box
+// (`intersect(ray, getBoundingBox())`; centre c, half h), takes up to 256 steps and never leaves early.
+__device__ __forceinline__ bool fractal_march(f3 lo, f3 ld, f3 c, f3 h, f3& hit) {
+    f3 p;
+    if (!hit_rect(lo - c, ld, h, p)) return false;   // intersect(Ray, AxisAlignedBox) src/Geometry.cpp:254-261
+    p = p + c;
+    for (int i = 0; i < 256; ++i) {
+        const float dist = fractal_sdf(p);
+        if (dist < 1e-3f) {
+            hit = p;
+            return true;
+        }
+        p = p + dist * ld;
+    }
+    return false;
+}
+__device__ __forceinline__ f3 fractal_normal(f3 p) {   // deflectLocalRay :177-189, central differences
+    const float delta = 1e-3f;
+    const f3 dx = mk3(delta, 0.0f, 0.0f), dy = mk3(0.0f, delta, 0.0f), dz = mk3(0.0f, 0.0f, delta);
+    const f3 g = mk3(fractal_sdf(p + dx) - fractal_sdf(p - dx), fractal_sdf(p + dy) - fractal_sdf(p - dy), fractal_sdf(p + dz) - fractal_sdf(p - dz));
+    return unit(mk3(g.x / delta, g.y / delta, g.z / delta));
+}
+
+// =============================================================================================
 // Camera ray of sample `sample` of pixel (x, y): Renderer::doWork's sample set-up (src/Renderer.cpp:72-94)
 // + Camera::getViewRay (src/Camera.cpp:65-81).  (sx0, sy0) = (x / (w - 1), y / (h - 1)) is the same for
 // every sample of the pixel and is passed in.
@@ -801,6 +839,23 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
                 const PrimRec* pr = sc.prims + prim;
                 const f3 lo = aff_pos(pr->inv, o);
                 const f3 ld = lin_mul(pr->inv, d);
+                if (pr->kind == 4u) {
+                    // FractalObject: the whole march here and now; p[0..5] hold its world box
+                    f3 hp;
+                    if (fractal_march(lo, ld, mk3(pr->p[0], pr->p[1], pr->p[2]), mk3(pr->p[3], pr->p[4], pr->p[5]), hp)) {
+                        const f3 w = aff_pos(pr->fwd, hp);
+                        const float t = dot(w - o, d);
+                        const unsigned long long key = make_key(t, prim);
+                        if (key < best) {
+                            best = key;
+                            best_pos = w;
+                            improved = true;
+                            limit = fmaxf(t, 0.0f) * inv_len2 * 1.00001f + 1e-6f;
+                        }
+                    }
+                    ++k;
+                    continue;
+                }
                 off = mk3(pr->p[0], pr->p[1], pr->p[2]);
                 crater_base = __float_as_uint(pr->p[3]);
                 crater_count = __float_as_uint(pr->p[4]);
@@ -910,7 +965,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
                 const uint32_t prim = static_cast<uint32_t>(key & 0xffffffffu);
                 PrimRegs pr;
                 load_prim(sc.prims, prim, pr);
-                if (pr.kind == 3u) {
+                if (pr.kind >= 3u) {   // SDF objects: normals need SDF evaluations
                     to_sdf = true;
                 } else {
                     const f3 wp = ld3(pb.hit_pos[slot]);
@@ -967,8 +1022,9 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
         const bool valid = i < n;
         uint32_t slot = 0, crater_base = 0, crater_count = 0;
         PrimRegs pr;
-        f3 wp = mk3(0, 0, 0), ld = mk3(0, 0, 0), p = mk3(0, 0, 0), off = mk3(0, 0, 0);
+        f3 wp = mk3(0, 0, 0), ld = mk3(0, 0, 0), p = mk3(0, 0, 0), off = mk3(0, 0, 0), local_hit = mk3(0, 0, 0);
         float s = 0.0f;
+        bool fractal = false;
         if (valid) {
             slot = pb.sdf_shade_queue[i];
             const uint32_t prim = static_cast<uint32_t>(pb.hit_key[slot] & 0xffffffffu);
@@ -977,22 +1033,31 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
             const f3 d = ld3(pb.ray_d[slot]);
             ld = lin_mul(pr.inv, d);
             const f3 lp = aff_pos(pr.inv, wp);
-            off = mk3(pr.p[0], pr.p[1], pr.p[2]);
-            crater_base = __float_as_uint(pr.p[3]);
-            crater_count = __float_as_uint(pr.p[4]);
-            p = mk3(lp.x + (e == 1u ? delta : 0.0f), lp.y + (e == 2u ? delta : 0.0f), lp.z + (e == 3u ? delta : 0.0f));
-            s = norm(p) - 0.5f;
-            ++c_evals;
+            fractal = pr.kind == 4u;
+            local_hit = lp;
+            if (!fractal) {
+                off = mk3(pr.p[0], pr.p[1], pr.p[2]);
+                crater_base = __float_as_uint(pr.p[3]);
+                crater_count = __float_as_uint(pr.p[4]);
+                p = mk3(lp.x + (e == 1u ? delta : 0.0f), lp.y + (e == 2u ? delta : 0.0f), lp.z + (e == 3u ? delta : 0.0f));
+                s = norm(p) - 0.5f;
+                ++c_evals;
+            }
         }
         // the far field returns the sphere distance itself (`sdf_sphere > 0.1` compares against a double literal)
-        const bool wants = valid && !(static_cast<double>(s) > 0.1);
+        const bool wants = valid && !fractal && !(static_cast<double>(s) > 0.1);
         float v = s;
         wave_near(sc.craters, cl, lds, lane, bp.lane_threshold, wants, p, off, s, crater_base, crater_count, v, c_near, c_noise);
         const float v0 = dpp_f<0x00>(0.0f, v), v1 = dpp_f<0x55>(0.0f, v), v2 = dpp_f<0xAA>(0.0f, v), v3 = dpp_f<0xFF>(0.0f, v);   // quad broadcasts
         bool alive = false;
         if (valid && e == 0u) {
-            const f3 g = mk3(v1 - v0, v2 - v0, v3 - v0) * (1.0f / delta);
-            const f3 nrm = unit(g);
+            f3 nrm;
+            if (fractal) {
+                nrm = fractal_normal(local_hit);   // six cheap evaluations on the quad's first lane
+            } else {
+                const f3 g = mk3(v1 - v0, v2 - v0, v3 - v0) * (1.0f / delta);
+                nrm = unit(g);
+            }
             const uint32_t s_local = slot / bp.n_pix;
             Rng rng(bp.seed, slot - s_local * bp.n_pix, bp.first_sample + s_local, 1u + bounce);
             const Bounce b = deflect(sc.materials[pr.material], ld, nrm, rng);

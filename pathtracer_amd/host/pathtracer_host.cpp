@@ -405,6 +405,11 @@ ColorBounce FractalObject::deflectLocalRay(const Ray& ray) const noexcept {
     return material.deflect(ray.dir, n);
 }
 AxisAlignedBox FractalObject::getLocalBoundingBox() const noexcept { return AxisAlignedBox(Pos(0.0f, 0.0f, 0.0f), Vec(2.0f, 2.0f, 2.0f)); }
+void FractalObject::describeForDevice(mipt_host::DevicePrimitive& o) const noexcept {
+    o.kind = MIPT_FRACTAL;
+    o.material = &material;
+    o.type_name = "FractalObject";
+}
 float FractalObject::signedDistance(const Pos& p) const noexcept {
     const auto fold = [](float v) {
         if (v < -0.5f) return v + 0.5f;
@@ -641,7 +646,7 @@ mipt_scene* sync_scene(const Scene& scene) {
         objs[i]->describeForDevice(d);
         if (d.kind < 0 || !d.material) {
             std::fprintf(stderr,
-                         "pathtracer: object %zu (type %s) has no device counterpart: supported are SphereObject, BoxObject, TriangleObject, the demo's "
+                         "pathtracer: object %zu (type %s) has no device counterpart: supported are SphereObject, BoxObject, TriangleObject, FractalObject, the demo's "
                          "CraterBallObject and SDF classes that specialise mipt_host::DeviceSdf.\n",
                          i, d.type_name);
             std::abort();

@@ -57,6 +57,12 @@ def test_renderer_class_matches_c_abi(ctx):
     got = host.scene(flat).render(cam, 48, 36, 8, 4, seed=1, threads=1)
     want, _ = ctx.render(ctx.upload(flat), cam, 48, 36, 8, 4, seed=DEFAULT_SEED)
     assert np.array_equal(got, want)
+    # a scene with a FractalObject goes to the device as well
+    flat, cam = G.fractal_scene(alg), G.fractal_camera(alg)
+    got = host.scene(flat).render(cam, 40, 40, 6, 4, seed=1, threads=1)
+    want, st = ctx.render(ctx.upload(flat), cam, 40, 40, 6, 4, seed=DEFAULT_SEED)
+    assert st["sdf_shades"] > 50
+    assert np.array_equal(got, want)
     hdr = np.random.RandomState(3).gamma(0.6, 2.0, (30, 50, 3)).astype(np.float32)
     for kind in (0, 1):
         assert np.array_equal(host.tonemap(kind, hdr), ctx.tonemap(kind, hdr))

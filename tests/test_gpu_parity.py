@@ -283,3 +283,40 @@ def test_sdf_value_is_independent_of_evaluator():
         for key in ("rays", "sdf_rays", "sdf_shades", "sdf_near_evals", "sdf_far_evals", "sdf_noise_calls", "shade_noise_calls"):
             assert st[key] == frames[0][1][key], key
     assert frames[0][1]["sdf_near_evals"] > 10000
+
+
+def test_fractal_object_is_exact(ctx, alg, oracle, golden):
+    """FractalObject (src/Object.cpp:160-252) is marched with exact arithmetic in the reference's order:
+    primary hits equal the reference's fixture and the oracle bit for bit, traced paths and images with
+    shared random numbers meet the analytic bars."""
+    flat, cam = G.fractal_scene(alg), G.fractal_camera(alg)
+    ds = ctx.upload(flat)
+    assert ds.info()["sdf"] == 1
+    got_prim, got_t = ctx.primary_hits(ds, cam, 64, 64)
+    assert np.array_equal(golden["fr_primary_prim"], got_prim)
+    assert np.array_equal(golden["fr_primary_t"], got_t)
+    assert (got_prim == 0).sum() > 200
+    # a denser map against the oracle
+    want_prim, want_t = oracle.scene(flat).primary_hits(cam, 160, 160)
+    got_prim, got_t = ctx.primary_hits(ds, cam, 160, 160)
+    assert np.array_equal(want_prim, got_prim)
+    assert np.array_equal(want_t, got_t)
+    # traced rays aimed at the lattice
+    r = np.random.RandomState(12)
+    o = (np.array([0.3, -0.2, 0.5]) + _unit(r.normal(size=(3000, 3))) * 6.0).astype(np.float32)
+    d = _unit(np.array([0.3, -0.2, 0.5]) + r.uniform(-0.9, 0.9, (3000, 3)) - o)
+    osc = oracle.scene(flat)
+    want = osc.trace(o, d, 6, rng_mode=1, seed=31)
+    got, prim, t = ctx.trace_rays(ds, o, d, 6, seed=31, first_hit=True)
+    wp, wt, _ = osc.closest_hit(o, d)
+    assert np.array_equal(wp, prim)
+    assert np.array_equal(wt[wp >= 0], t[wp >= 0])
+    assert (wp == 0).sum() > 300
+    close = np.all(np.abs(want - got) <= 1e-4 * np.maximum(1.0, np.abs(want)), axis=1)
+    assert close.mean() >= 0.995, f"only {close.mean():.4f} of paths agree"
+    # image with shared random numbers
+    want, wstats = osc.render(cam, 48, 48, 6, 8, rng_mode=1, seed=9, threads=0, full_width=True)
+    got, gstats = ctx.render(ds, cam, 48, 48, 6, 8, seed=9)
+    assert abs(gstats["rays"] - wstats["rays"]) <= 2e-3 * wstats["rays"]
+    close = np.abs(want - got) <= 1e-4 * np.maximum(1.0, np.abs(want))
+    assert close.all(axis=2).mean() >= 0.99
