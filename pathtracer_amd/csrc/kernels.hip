@@ -690,7 +690,9 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
     __shared__ uint32_t s_pend[4 * kCap];
     PendingQueue to_sdf{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u};
     const uint32_t n = pb.counters[bounce].n_live;
-    if (n == 0) return;
+    // a short queue needs only its first workgroups (one block of 256 entries each); the rest would just
+    // queue up on the cursors to learn that nothing is left
+    if (static_cast<unsigned long long>(blockIdx.x) * 256u >= n) return;
     const uint32_t* queue = pb.queue[bounce & 1];
     uint32_t* heads = pb.counters[bounce].extend_head;
     int* stack = s_stack + threadIdx.x;

@@ -320,3 +320,4 @@ def test_fractal_object_is_exact(ctx, alg, oracle, golden):
     assert abs(gstats["rays"] - wstats["rays"]) <= 2e-3 * wstats["rays"]
     close = np.abs(want - got) <= 1e-4 * np.maximum(1.0, np.abs(want))
     assert close.all(axis=2).mean() >= 0.99
+
