@@ -518,8 +518,8 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     if (e == hipSuccess) e = upload(&s->d_sdf, sdf.data(), sdf.size() * sizeof(SdfBox));
     // noise() (PathTracerDemo.cpp:56-70) applies the transform T = (L, t), samples, scales by 1.1 and
     // repeats; octave i therefore samples q_i = A_i p + b_i with A_0 = L, b_0 = t, A_i = 1.1 L A_{i-1},
-    // b_i = 1.1 L b_{i-1} + t.  Composed in double, stored as float, so the 8 octaves of one call can be
-    // evaluated side by side.
+    // b_i = 1.1 L b_{i-1} + t.  Composed in double, stored as float (13 per octave: A row-major, b + 0.25,
+    // weight), so the 8 octaves of one call can be evaluated side by side.
     float oct[8 * 13] = {};
     if (any_sdf) {
         const float* nt = d->noise_transform;
@@ -529,7 +529,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
         float kf = 0.02f;
         for (int o = 0; o < 8; ++o) {
             for (int i = 0; i < 9; ++i) oct[13 * o + i] = static_cast<float>(A[i]);
-            for (int i = 0; i < 3; ++i) oct[13 * o + 9 + i] = static_cast<float>(bb[i]);
+            for (int i = 0; i < 3; ++i) oct[13 * o + 9 + i] = static_cast<float>(bb[i] + 0.25);   // the triangle wave's phase, folded in
             oct[13 * o + 12] = kf;
             kf *= 0.9f;
             double A2[9], b2[3];

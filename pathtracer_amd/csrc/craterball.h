@@ -227,42 +227,65 @@ __device__ __forceinline__ float near_total(float s, int big_fix, float crater_s
 
 // What each lane contributes to the cooperative parts of an evaluation.
 struct CoopLane {
-    float si, sj, sk;     // lanes 0-7 / 8-15 of a row: cell of the 2^3 small / tiny-crater neighbourhood (0..1)
-    float A[9], b[3], k;  // noise octave (lane & 7): q = A p + b is the point the octave samples, k its weight
+    float si, sj, sk;   // lanes 0-7 / 8-15 of a row: cell of the 2^3 small / tiny-crater neighbourhood (0..1)
+    float m0, m1;       // this lane's element of the two octave matrices (below)
+    float kw0, kw1;     // weights of octaves (lane >> 4) and 4 + (lane >> 4)
 };
+
+// noise() :56-70 is 8 octaves; octave o samples the triangle wave at q_o = A_o p + b_o (the composed
+// affine, 13 floats per octave in `noise_oct`: A row-major, b + 0.25, weight).  For 16 points at once
+// that is a 32 x 4 by 4 x 16 matrix product -- rows (octave, coordinate) padded to 4 per octave, columns
+// (x, y, z, 1) -- which two v_mfma_f32_16x16x4_f32 compute exactly (f32 FMA chains) while the vector
+// pipe does other waves' work.  Lane l supplies element [l & 15][l >> 4] of each 16 x 4 tile.
 __device__ __forceinline__ CoopLane make_coop_lane(const float* noise_oct, uint32_t lane) {
     CoopLane c;
     c.si = static_cast<float>((lane >> 2) & 1u);
     c.sj = static_cast<float>((lane >> 1) & 1u);
     c.sk = static_cast<float>(lane & 1u);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) c.A[i] = 0.0f;
-    c.b[0] = c.b[1] = c.b[2] = c.k = 0.0f;
+    c.m0 = c.m1 = c.kw0 = c.kw1 = 0.0f;
     if (!noise_oct) return c;   // a scene without crater balls carries no octave table (and never evaluates one)
-    const float* o = noise_oct + 13 * (lane & 7u);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) c.A[i] = o[i];
-    c.b[0] = o[9];
-    c.b[1] = o[10];
-    c.b[2] = o[11];
-    c.k = o[12];
+    const uint32_t row = lane & 15u, k = lane >> 4, coord = row & 3u;
+    if (coord < 3u) {
+        const uint32_t o0 = row >> 2, o1 = 4u + (row >> 2);
+        c.m0 = k < 3u ? noise_oct[13u * o0 + 3u * coord + k] : noise_oct[13u * o0 + 9u + coord];
+        c.m1 = k < 3u ? noise_oct[13u * o1 + 3u * coord + k] : noise_oct[13u * o1 + 9u + coord];
+    }
+    c.kw0 = noise_oct[13u * k + 12u];
+    c.kw1 = noise_oct[13u * (4u + k) + 12u];
     return c;
 }
 
-// noise() :56-70 for 8 points at once: lane l evaluates octave l & 7 of the point its group of 8 lanes
-// holds (octave i samples A_i p + b_i with the composed affine held per lane), and a DPP sum over the 8
-// lanes returns the call's value in every lane of the group.
-__device__ __forceinline__ float noise_octaves(const CoopLane& cl, float x, float y, float z) {
-    const float qx = fmaf(cl.A[0], x, fmaf(cl.A[1], y, fmaf(cl.A[2], z, cl.b[0])));
-    const float qy = fmaf(cl.A[3], x, fmaf(cl.A[4], y, fmaf(cl.A[5], z, cl.b[1])));
-    const float qz = fmaf(cl.A[6], x, fmaf(cl.A[7], y, fmaf(cl.A[8], z, cl.b[2])));
+typedef float mipt_f32x4 __attribute__((ext_vector_type(4)));
+
+// noise() for 16 points at once: the matrix products, then the triangle waves and the sum over octaves.
+// `coord` is coordinate (lane >> 4) of point (lane & 15), and 1 on lanes 48-63; every lane gets the value
+// of point (lane & 15).  All 64 lanes must be active.
+struct Noise16 {
+    mipt_f32x4 q0, q1;   // q (+ 0.25) of octave (lane >> 4), resp. 4 + (lane >> 4), at point (lane & 15)
+};
+__device__ __forceinline__ Noise16 noise16_start(const CoopLane& cl, float coord) {
+    const mipt_f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    Noise16 n;
+    n.q0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cl.m0, coord, zero, 0, 0, 0);
+    n.q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cl.m1, coord, zero, 0, 0, 0);
+    return n;
+}
+__device__ __forceinline__ float noise16_finish(const CoopLane& cl, const Noise16& n) {
     // triangle(v) = -1 + 4 |v - 0.25 - floor(v + 0.25)| = 4 |fract(v + 0.25) - 0.5| - 1  (:26-28)
-    const float a = (fabsf(__builtin_amdgcn_fractf(qx + 0.25f) - 0.5f) + fabsf(__builtin_amdgcn_fractf(qy + 0.25f) - 0.5f)) +
-                    fabsf(__builtin_amdgcn_fractf(qz + 0.25f) - 0.5f);
-    float v = cl.k * a;
-    v += dpp_f<kQuadXor1>(0.0f, v);
-    v += dpp_f<kQuadXor2>(0.0f, v);
-    v += dpp_f<kRowHalfMirror>(0.0f, v);
+    const float a0 = (fabsf(__builtin_amdgcn_fractf(n.q0.x) - 0.5f) + fabsf(__builtin_amdgcn_fractf(n.q0.y) - 0.5f)) + fabsf(__builtin_amdgcn_fractf(n.q0.z) - 0.5f);
+    const float a1 = (fabsf(__builtin_amdgcn_fractf(n.q1.x) - 0.5f) + fabsf(__builtin_amdgcn_fractf(n.q1.y) - 0.5f)) + fabsf(__builtin_amdgcn_fractf(n.q1.z) - 0.5f);
+    float v = fmaf(cl.kw1, a1, cl.kw0 * a0);
+    // sum over the four rows of 16 lanes: rows 0+1 and 2+3, then the two halves
+    {
+        const unsigned u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const unsigned u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
     // noise = sum_i k_i (4 a_i - 3) with sum_i k_i = 0.02 (1 - 0.9^8) / 0.1
     return fmaf(4.0f, v, -3.0f * 0.11390656f);
 }
@@ -274,8 +297,8 @@ __device__ __forceinline__ float noise_octaves(const CoopLane& cl, float x, floa
 //
 //   * lane l holds crater l of the ball's table (r0..r2; lanes past the table hold a cell out of
 //     anyone's reach), one pass per point;
-//   * noise() calls -- two per big crater that deposits fallout, two for the final terms -- run as
-//     (point, octave) tasks, 8 calls per round; the calls of all G points share the rounds;
+//   * noise() calls -- two per big crater that deposits fallout, two for the final terms -- run 16 at
+//     a time on the matrix core; the calls of all G points share the rounds;
 //   * the 8 small-crater and 8 tiny-crater cells of point g run on the 16 lanes of DPP row g; the
 //     order dependence of the small craters through min_age is an exclusive prefix minimum.
 //
@@ -283,7 +306,7 @@ __device__ __forceinline__ float noise_octaves(const CoopLane& cl, float x, floa
 // rounds, so the 256-step worst case of a march is a fraction of a millisecond.
 // =============================================================================================
 constexpr int kCoopGroup = 4;                                    // points one wave evaluates together
-constexpr int kCoopPts = 2 * 64 * kCoopGroup + 2 * kCoopGroup;   // fallout points + final points (a multiple of 8)
+constexpr int kCoopPts = 2 * 64 * kCoopGroup + 16;               // fallout points + final points, rounded up to whole rounds of 16
 constexpr int kCoopLdsFloats = 4 * kCoopPts;                     // x, y, z, value
 
 template <int G>
@@ -344,21 +367,21 @@ __device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, float4
     }
     wave_lds_fence();
 
-    // ---- noise() as (point, octave) tasks: 8 points per round ---------------------------------
+    // ---- noise(): 16 points per round ------------------------------------------------------------
     // (the next round's arguments are fetched before this round computes, so LDS latency stays hidden;
     // slots past n_pts hold stale data whose values are never used)
     {
-        uint32_t slot = lane >> 3;
-        float x = px[slot], y = py[slot], z = pz[slot];
-        for (uint32_t first = 0; first < n_pts; first += 8u) {
-            const uint32_t next = slot + 8u < static_cast<uint32_t>(kCoopPts) ? slot + 8u : slot;
-            const float nx = px[next], ny = py[next], nz = pz[next];
-            const float v = noise_octaves(cl, x, y, z);
-            if ((lane & 7u) == 0u) pv[slot] = v;
+        const uint32_t plane = min(lane >> 4, 2u) * static_cast<uint32_t>(kCoopPts);   // x, y or z array of this lane's coordinate
+        const bool is_one = lane >= 48u;
+        uint32_t slot = lane & 15u;
+        float coord = lds[plane + slot];
+        for (uint32_t first = 0; first < n_pts; first += 16u) {
+            const uint32_t next = slot + 16u < static_cast<uint32_t>(kCoopPts) ? slot + 16u : slot;
+            const float next_coord = lds[plane + next];
+            const float v = noise16_finish(cl, noise16_start(cl, is_one ? 1.0f : coord));
+            if (lane < 16u) pv[slot] = v;
             slot = next;
-            x = nx;
-            y = ny;
-            z = nz;
+            coord = next_coord;
         }
     }
     wave_lds_fence();
@@ -411,8 +434,8 @@ __device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, float4
 // lane_near: one point per lane.  A wave-uniform loop walks the ball's crater table (lane c holds crater
 // c; the loop reads it into scalar registers with readlane, so no step waits for memory), the small and
 // tiny craters go cell by cell, and only noise() stays cooperative: every
-// lane stages the arguments of its calls in a ring in LDS, and rounds of 8 calls x 8 octaves drain the
-// ring whenever half of it is full, writing each value to the LDS slot its owner named.
+// lane stages the arguments of its calls in a ring in LDS, and rounds of 16 calls drain the ring whenever
+// half of it is full, writing each value to the LDS slot its owner named.
 // =============================================================================================
 constexpr int kRing = 256;          // staged noise() arguments; one crater step adds at most 128
 constexpr int kLaneDeposits = 8;    // fallout deposits one lane can hold; a point with more is left to the caller
@@ -421,26 +444,23 @@ constexpr int kNearLdsFloats = kLaneLdsFloats > kCoopLdsFloats ? kLaneLdsFloats 
 
 __device__ __forceinline__ void noise_ring_rounds(const CoopLane& cl, float* lds, uint32_t lane, uint32_t& done, uint32_t staged, bool flush_all) {
     wave_lds_fence();
-    const float* rx = lds;
-    const float* ry = lds + kRing;
-    const float* rz = lds + 2 * kRing;
     const uint32_t* rt = reinterpret_cast<const uint32_t*>(lds + 3 * kRing);
-    // the next round's arguments are fetched before this round computes, so LDS latency stays hidden
-    uint32_t call = done + (lane >> 3);
+    const uint32_t plane = min(lane >> 4, 2u) * static_cast<uint32_t>(kRing);   // x, y or z array of this lane's coordinate
+    const bool is_one = lane >= 48u;
+    // 16 calls per round; the next round's arguments are fetched before this round computes
+    uint32_t call = done + (lane & 15u);
     uint32_t slot = call & (kRing - 1);
-    float x = rx[slot], y = ry[slot], z = rz[slot];
+    float coord = lds[plane + slot];
     uint32_t target = rt[slot];
-    while (flush_all ? done < staged : done + 8u <= staged) {
-        const uint32_t next = (call + 8u) & (kRing - 1);
-        const float nx = rx[next], ny = ry[next], nz = rz[next];
+    while (flush_all ? done < staged : done + 16u <= staged) {
+        const uint32_t next = (call + 16u) & (kRing - 1);
+        const float next_coord = lds[plane + next];
         const uint32_t next_target = rt[next];
-        const float v = noise_octaves(cl, x, y, z);
-        if ((lane & 7u) == 0u && call < staged) lds[target] = v;
-        done += 8u;
-        call += 8u;
-        x = nx;
-        y = ny;
-        z = nz;
+        const float v = noise16_finish(cl, noise16_start(cl, is_one ? 1.0f : coord));
+        if (lane < 16u && call < staged) lds[target] = v;
+        done += 16u;
+        call += 16u;
+        coord = next_coord;
         target = next_target;
     }
     if (done > staged) done = staged;

@@ -59,7 +59,7 @@ struct SceneDev {
     uint32_t n_sdf;
     uint32_t n_prims;
     // noise() (PathTracerDemo.cpp:56-70) unrolled: octave i samples A_i p + b_i with weight k_i; 13 floats per octave (A row-major,
-    // b, k), 8 octaves (null when the scene has no SDF primitive)
+    // b + 0.25, k), 8 octaves (null when the scene has no crater ball)
     const float* noise_oct;
     // big craters of every crater ball: 12 floats per crater {cell.xyz, size, on_sphere.xyz, t, age bits, 1/(5 size), -, -};
     // a ball's records start at record PrimRec::p[3] and number PrimRec::p[4] (both uint32 bit patterns)
