@@ -10,7 +10,7 @@ the GPU and copied to the host on rank 0.  Samples are addressed by their global
 is the same set of samples for every N (strong scaling: the total work per frame is fixed).
 
 Rank 0 prints one JSON line.  `value` is Mpaths/s over the whole job; `roofline` prices the dominant
-kernel (the SDF march: VALU-bound, no MFMA, almost no memory traffic) from HIP events recorded around
+kernel (the SDF march: bound by vector instruction issue, almost no memory traffic) from HIP events recorded around
 each of its launches inside the timed region; `cpu_baseline` is the CPU restatement of the reference
 renderer (oracle/, minstd_rand0 sampling, 8-pixel tasks) on a bounded sample of the same workload.
 """
@@ -185,7 +185,8 @@ def main():
         out["roofline"] = {"kernel": "k_sdf_march", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS,
                            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": None,
                            "avg_launch_ms": avg_ms, "launches": n_launch,
-                           "note": "fp32 vector (no MFMA: nothing on this path is a dense contraction); flops = far*12 + near*6080 + noise*376"}
+                           "note": "fp32 vector peak; the octave transforms of noise() run on the f32 matrix core, whose peak is the same 157.3; "
+                                   "flops = far*12 + near*6080 + noise*376 (the reference's arithmetic)"}
     elif dominant is not None:
         # analytic scenes: traversal is a gather of 64-byte nodes and 128-byte primitive lines
         n_launch = max(1, launches[dominant])
