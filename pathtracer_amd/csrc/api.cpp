@@ -29,7 +29,7 @@ struct mipt_ctx {
     std::mutex mutex;   // render calls are serialised, as Renderer::render is (src/Renderer.cpp:144)
 
     // working set, grown on demand and kept between calls
-    size_t slots_cap = 0;
+    size_t slots_cap = 0, bits_cap = 0;
     PathBuffers pb{};
     void* arena = nullptr;
     float* frame = nullptr;          // per-call radiance sum (mipt_render)
@@ -75,7 +75,7 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-constexpr size_t kBytesPerSlot = 4 * 16 + 8 + 16 + 4 * 4;   // rays, attenuation, radiance, hit key, hit position, four queues
+constexpr size_t kBytesPerSlot = 4 * 16 + 8 + 16 + 4 * 4 + 1;   // rays, attenuation, radiance, hit key, hit position, four queues, bitmap (rounded up)
 constexpr size_t kMaxSlots = (size_t(1) << 31) - 256;      // slot indices are 32-bit
 
 // Paths in flight per sample batch.  Large batches matter: every bounce of every batch ends in a
@@ -95,13 +95,17 @@ size_t batch_path_budget(const mipt_ctx* c) {
     return std::min(std::max(budget, size_t(1) << 20), kMaxSlots);
 }
 
-int ensure_slots(mipt_ctx* c, size_t slots) {
-    if (slots <= c->slots_cap) return MIPT_OK;
+// `words`: 64-bit words of the live-path bitmap (samples * ceil(pixels / 64)).
+int ensure_slots(mipt_ctx* c, size_t slots, size_t words) {
+    if (slots <= c->slots_cap && words <= c->bits_cap) return MIPT_OK;
+    slots = std::max(slots, c->slots_cap);
+    words = std::max(words, c->bits_cap);
     if (c->arena) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipFree(c->arena));
         c->arena = nullptr;
         c->slots_cap = 0;
+        c->bits_cap = 0;
     }
     const size_t n = align_up(slots, 256);
     size_t off = 0;
@@ -115,6 +119,7 @@ int ensure_slots(mipt_ctx* c, size_t slots) {
     const size_t o_q0 = take(n * 4), o_q1 = take(n * 4), o_qs = take(n * 4), o_qss = take(n * 4);
     const size_t o_cnt = take(sizeof(BounceCounters) * (kMaxBounces + 1));
     const size_t o_tot = take(sizeof(Totals));
+    const size_t o_bits = take(words * 8);
     void* base = nullptr;
     const hipError_t e = hipMalloc(&base, off);
     if (e != hipSuccess) {
@@ -136,6 +141,8 @@ int ensure_slots(mipt_ctx* c, size_t slots) {
     c->pb.sdf_shade_queue = reinterpret_cast<uint32_t*>(b + o_qss);
     c->pb.counters = reinterpret_cast<BounceCounters*>(b + o_cnt);
     c->pb.totals = reinterpret_cast<Totals*>(b + o_tot);
+    c->pb.live_bits = reinterpret_cast<unsigned long long*>(b + o_bits);
+    c->bits_cap = words;
     return MIPT_OK;
 }
 
@@ -226,7 +233,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         const size_t n_batches = (st->spp + per_batch_max - 1) / per_batch_max;
         per_batch = static_cast<uint32_t>((st->spp + n_batches - 1) / n_batches);
         if (n_pix * per_batch > kMaxSlots) return MIPT_ERR_TOO_LARGE;
-        const int rc = ensure_slots(c, n_pix * per_batch);
+        const int rc = ensure_slots(c, n_pix * per_batch, static_cast<size_t>(per_batch) * ((n_pix + 63) / 64));
         if (rc == MIPT_OK) break;
         if (rc != MIPT_ERR_OUT_OF_MEMORY || per_batch == 1) return rc;
         (void)hipGetLastError();
@@ -255,7 +262,6 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.lane_threshold = c->lane_threshold;
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->pb.rad, 0, sizeof(float4) * bp.n_slots, c->stream));   // paths that hit nothing stay black
         { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate_extend(c->stream, cr, sc->dev, bp, c->pb, sc->depth); }
         enqueue_bounces(c, sc, bp, st->bounces, 1);
         { StageTimer t(c, MIPT_STAGE_ACCUMULATE); launch_accumulate(c->stream, bp, c->pb, d_sum); }
@@ -621,7 +627,7 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = static_cast<size_t>(width) * height;
     if (n > (size_t(1) << 28)) return MIPT_ERR_TOO_LARGE;
-    int rc = ensure_slots(c, n);
+    int rc = ensure_slots(c, n, (n + 63) / 64);
     if (rc != MIPT_OK) return rc;
     BatchParams bp{};
     bp.n_pix = bp.n_slots = static_cast<uint32_t>(n);
@@ -659,7 +665,7 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     if (bounces > static_cast<uint32_t>(kMaxBounces) || n > (1u << 28)) return MIPT_ERR_TOO_LARGE;
     std::lock_guard<std::mutex> lock(c->mutex);
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_slots(c, n);
+    int rc = ensure_slots(c, n, 1);
     if (rc != MIPT_OK) return rc;
     rc = ensure_floats(c, &c->stage, &c->stage_cap, static_cast<size_t>(n) * 6);
     if (rc != MIPT_OK) return rc;

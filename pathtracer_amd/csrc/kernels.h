@@ -21,6 +21,9 @@ struct PathBuffers {
     uint32_t* sdf_shade_queue;   // slots whose closest hit is an SDF primitive
     BounceCounters* counters;    // kMaxBounces + 1 entries
     Totals* totals;
+    // one bit per slot, set for the paths whose primary ray hit something or reached an SDF box (only
+    // those ever carry radiance); sample s of pixel p is bit p & 63 of word s * ceil(n_pix / 64) + p / 64
+    unsigned long long* live_bits;
 };
 
 struct BatchParams {

@@ -641,6 +641,8 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
     }
     uint32_t n_sdf_rays = 0;
     uint32_t s_next = in_image ? blockIdx.y : samples;   // this lane's next sample
+    uint32_t s_cur = blockIdx.y - gridDim.y;             // wave-uniform (wraps; advanced before use)
+    const uint32_t words_per_sample = (bp.n_pix + 63u) / 64u;
     Trav t;
     t.busy = false;
     for (;;) {
@@ -652,6 +654,7 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
             s_next += gridDim.y;
         }
         if (!__ballot(t.busy)) break;
+        s_cur += gridDim.y;   // the sample the wave works on now (its lanes move through the samples together)
         // The wave's 64 rays of one sample run to the end together: neighbouring pixels take about equally
         // long, and their queue entries then name 64 consecutive slots, which is what lets the kernels that
         // read the queue later fetch the paths' state in full cache lines.
@@ -667,8 +670,15 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
                 pb.ray_d[t.slot] = st4(t.d);
                 pb.hit_key[t.slot] = t.best;
                 pb.hit_pos[t.slot] = st4(t.best_pos);
+                pb.rad[t.slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // stays black unless a hit adds light
             }
             t.busy = false;
+        }
+        // which of this wave's 64 paths of the sample carry on: one word of the batch's bitmap (written for
+        // every wave and sample, so the bitmap needs no clearing)
+        {
+            const unsigned long long kept = __ballot(keep);
+            if ((threadIdx.x & 63u) == 0u) pb.live_bits[static_cast<size_t>(s_cur) * words_per_sample + (pix >> 6)] = kept;
         }
         pending_push(live, keep, t.slot, &pb.counters[0].n_live, pb.queue[0]);
         pending_push(to_sdf, wants_sdf, t.slot, &pb.counters[0].n_sdf, pb.sdf_queue);
@@ -1081,18 +1091,39 @@ __global__ void k_finish_batch(PathBuffers pb, uint32_t bounces, uint32_t n_slot
     pb.totals->rays += rays;
 }
 
-// frame[pix] += sample 0 + sample 1 + ... of this batch, sequentially in sample order
+// frame[pix] += sample 0 + sample 1 + ... of this batch, sequentially in sample order.  Only the paths
+// marked in the batch's bitmap carry radiance; the others would add exactly zero and are not read.
 __global__ void __launch_bounds__(256) k_accumulate(BatchParams bp, PathBuffers pb, float* frame) {
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t samples = bp.n_slots / bp.n_pix;
+    const uint32_t words_per_sample = (bp.n_pix + 63u) / 64u;
     for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < bp.n_pix; pix += stride) {
         float r = frame[3 * pix], g = frame[3 * pix + 1], b = frame[3 * pix + 2];
-        for (uint32_t s = 0; s < samples; ++s) {
-            const float4 c = pb.rad[s * bp.n_pix + pix];
-            r += c.x;
-            g += c.y;
-            b += c.z;
+        const unsigned long long* bits = pb.live_bits + (pix >> 6);
+        const uint32_t bit = pix & 63u;
+        uint32_t s = 0;
+        for (; s + 4u <= samples; s += 4u) {   // four bitmap words in flight
+            const unsigned long long m0 = bits[static_cast<size_t>(s) * words_per_sample];
+            const unsigned long long m1 = bits[static_cast<size_t>(s + 1u) * words_per_sample];
+            const unsigned long long m2 = bits[static_cast<size_t>(s + 2u) * words_per_sample];
+            const unsigned long long m3 = bits[static_cast<size_t>(s + 3u) * words_per_sample];
+            const unsigned long long m[4] = {m0, m1, m2, m3};
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k)
+                if ((m[k] >> bit) & 1ull) {
+                    const float4 c = pb.rad[(s + k) * bp.n_pix + pix];
+                    r += c.x;
+                    g += c.y;
+                    b += c.z;
+                }
         }
+        for (; s < samples; ++s)
+            if ((bits[static_cast<size_t>(s) * words_per_sample] >> bit) & 1ull) {
+                const float4 c = pb.rad[s * bp.n_pix + pix];
+                r += c.x;
+                g += c.y;
+                b += c.z;
+            }
         frame[3 * pix] = r;
         frame[3 * pix + 1] = g;
         frame[3 * pix + 2] = b;
