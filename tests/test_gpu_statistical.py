@@ -2,7 +2,7 @@
 (tests/golden/reference_converged.npz, rendered by oracle/_ref/libref.so with two seeds).
 
 The reference draws from minstd_rand0 and the device from its counter generator, so only statistics
-can agree.  Acceptance (BASELINE.md section 4): RMSE(GPU, ref A) <= 1.25 x RMSE(ref A, ref B), the
+can agree.  Acceptance: RMSE(GPU, ref A) <= 1.25 x RMSE(ref A, ref B), the
 reference's own seed-to-seed noise floor, and the mean relative error of the 8x8 box-filtered images
 <= 2 %."""
 import os
