@@ -175,7 +175,7 @@ def main():
     launches = agg.get("stage_launches", {})
     out["stage_ms_per_step"] = {k: round(v / a.steps, 3) for k, v in stage_ms.items()}
     out["work_per_step"] = {k: agg[k] // a.steps for k in ("paths", "rays", "sdf_rays", "sdf_shades", "sdf_far_evals", "sdf_near_evals",
-                                                            "sdf_noise_calls", "shade_evals", "shade_noise_calls") if k in agg}
+                                                            "sdf_noise_calls", "shade_evals", "shade_noise_calls", "primary_traced") if k in agg}
     dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
     if dominant == "sdf_march":
         flops = (agg["sdf_far_evals"] * FLOP_FAR_EVAL + agg["sdf_near_evals"] * FLOP_NEAR_BODY + agg["sdf_noise_calls"] * FLOP_NOISE_CALL)

@@ -107,6 +107,10 @@ typedef struct {
      * accumulate. */
     double   stage_ms[6];
     uint64_t stage_launches[6];
+    /* Primary rays that were actually traced.  `rays` counts every closest-hit query the frame asks, as
+     * the reference would make them; the queries of pixels that lie outside the screen bounds of every
+     * object are answered (miss) without a ray. */
+    uint64_t primary_traced;
 } mipt_stats;
 
 enum { MIPT_STAGE_GENERATE = 0, MIPT_STAGE_EXTEND = 1, MIPT_STAGE_SDF_MARCH = 2, MIPT_STAGE_SHADE = 3,

@@ -127,7 +127,8 @@ class Context:
                     sdf_noise_calls=int(st.sdf_noise_calls), shade_evals=int(st.shade_evals),
                     shade_noise_calls=int(st.shade_noise_calls), ms_device=float(st.ms_device),
                     stage_ms=dict(zip(STAGES, (float(x) for x in st.stage_ms))),
-                    stage_launches=dict(zip(STAGES, (int(x) for x in st.stage_launches))))
+                    stage_launches=dict(zip(STAGES, (int(x) for x in st.stage_launches))),
+                    primary_traced=int(st.primary_traced))
 
     def render(self, scene, cam16, w, h, bounces, spp, seed=1, first_sample=0, flags=0):
         """Renderer::render: (h, w, 3) float32 mean image and the call's statistics."""

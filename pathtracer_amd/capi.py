@@ -44,7 +44,8 @@ class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("sdf_rays", C.c_uint64), ("sdf_shades", C.c_uint64),
                 ("sdf_far_evals", C.c_uint64), ("sdf_near_evals", C.c_uint64), ("sdf_noise_calls", C.c_uint64),
                 ("shade_evals", C.c_uint64), ("shade_noise_calls", C.c_uint64),
-                ("ms_device", C.c_double), ("stage_ms", C.c_double * 6), ("stage_launches", C.c_uint64 * 6)]
+                ("ms_device", C.c_double), ("stage_ms", C.c_double * 6), ("stage_launches", C.c_uint64 * 6),
+                ("primary_traced", C.c_uint64)]
 
 
 EXPORTS = [

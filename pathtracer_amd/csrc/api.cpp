@@ -5,10 +5,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -60,6 +62,9 @@ struct mipt_scene {
     void* d_craters = nullptr;
     uint32_t n_nodes = 0, n_analytic = 0, n_sdf = 0;
     int depth = 0;
+    // padded world boxes that together hold everything a ray can hit: the analytic primitives' common
+    // box and the SDF primitives' boxes (merged into one if there are many)
+    std::vector<std::array<float, 6>> cull_boxes;
 };
 
 namespace {
@@ -175,6 +180,80 @@ CameraRec pack_camera(const mipt_camera& cam) {
     return r;
 }
 
+// Screen bounds of the scene's boxes for this camera (pixels, inclusive, two pixels of margin for the
+// sub-pixel jitter and rounding).  Camera::getViewRay (src/Camera.cpp:65-81) without lens blur sends the ray
+// of screen point (u, v) from T (u, v, 0) along L (k u, k v, 1), k = tan(fov): in the camera's frame every ray
+// passes through (0, 0, -1/k), so a point (X, Y, Z) is seen at (u, v) = (X, Y) / (1 + k Z).  A box whose
+// corners all have 1 + k Z > 0 projects inside the bounds of its projected corners; anything else, or
+// a lens with blur, gives up and returns the whole frame.
+CullRects screen_rects(const mipt_scene* sc, const mipt_camera& cam, uint32_t W, uint32_t H) {
+    CullRects full{};
+    full.n = 1;
+    full.r[0][0] = 0;
+    full.r[0][1] = 0;
+    full.r[0][2] = static_cast<int>(W) - 1;
+    full.r[0][3] = static_cast<int>(H) - 1;
+    if (cam.blur_radius != 0.0f || sc->cull_boxes.empty() || sc->cull_boxes.size() > 8) return full;
+    const float* m = cam.transform;
+    const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    if (!(std::fabs(det) > 1e-300)) return full;
+    const double inv[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det, (f * g - d * i) / det, (a * i - c * g) / det,
+                           (c * d - a * f) / det, (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+    const double k = std::tan(static_cast<double>(cam.fov_degrees) * 3.141592653589793 / 180.0);
+    const double aspect = cam.aspect;
+    CullRects out{};
+    for (const auto& box : sc->cull_boxes) {
+        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+        double pc[8][3];
+        for (int corner = 0; corner < 8; ++corner) {
+            const double p[3] = {(corner & 1 ? box[3] : box[0]) - static_cast<double>(m[9]), (corner & 2 ? box[4] : box[1]) - static_cast<double>(m[10]),
+                                 (corner & 4 ? box[5] : box[2]) - static_cast<double>(m[11])};
+            for (int r = 0; r < 3; ++r) pc[corner][r] = inv[3 * r] * p[0] + inv[3 * r + 1] * p[1] + inv[3 * r + 2] * p[2];
+            if (!std::isfinite(pc[corner][0]) || !std::isfinite(pc[corner][1]) || !std::isfinite(pc[corner][2])) return full;
+        }
+        // Rays leave the plane Z = 0 towards +Z, so only the part of the box with Z >= 0 can be hit: project
+        // the corners in front of the plane and the points where the box's edges cross it (there 1 + k Z >= 1).
+        bool any = false;
+        auto project = [&](double X, double Y, double Z) {
+            const double w = 1.0 + k * Z;
+            // screen point -> pixel: (u, v) = (vx, vy / aspect) for aspect > 1, else (vx * aspect, vy); vx = 2 x / (W - 1) - 1
+            const double u = X / w, v = Y / w;
+            const double vx = aspect > 1.0 ? u : u / aspect, vy = aspect > 1.0 ? v * aspect : v;
+            const double px = (vx + 1.0) * 0.5 * (W - 1.0), py = (vy + 1.0) * 0.5 * (H - 1.0);
+            x0 = std::min(x0, px);
+            x1 = std::max(x1, px);
+            y0 = std::min(y0, py);
+            y1 = std::max(y1, py);
+            any = true;
+        };
+        if (!(k >= 0.0)) return full;
+        for (int corner = 0; corner < 8; ++corner) {
+            if (pc[corner][2] >= 0.0) project(pc[corner][0], pc[corner][1], pc[corner][2]);
+            for (int axis = 0; axis < 3; ++axis) {
+                const int other = corner ^ (1 << axis);
+                if (other < corner) continue;
+                const double za = pc[corner][2], zb = pc[other][2];
+                if ((za < 0.0) != (zb < 0.0)) {
+                    const double t = za / (za - zb);
+                    project(pc[corner][0] + t * (pc[other][0] - pc[corner][0]), pc[corner][1] + t * (pc[other][1] - pc[corner][1]), 0.0);
+                }
+            }
+        }
+        if (!any) continue;   // wholly behind the plane the rays start from
+        const double lim = 1e9;
+        const int rx0 = static_cast<int>(std::floor(std::max(x0, -lim))) - 2, rx1 = static_cast<int>(std::ceil(std::min(x1, lim))) + 2;
+        const int ry0 = static_cast<int>(std::floor(std::max(y0, -lim))) - 2, ry1 = static_cast<int>(std::ceil(std::min(y1, lim))) + 2;
+        if (rx1 < 0 || ry1 < 0 || rx0 > static_cast<int>(W) - 1 || ry0 > static_cast<int>(H) - 1) continue;   // off screen
+        int* r = out.r[out.n++];
+        r[0] = std::max(rx0, 0);
+        r[1] = std::max(ry0, 0);
+        r[2] = std::min(rx1, static_cast<int>(W) - 1);
+        r[3] = std::min(ry1, static_cast<int>(H) - 1);
+    }
+    return out;
+}
+
 // Brackets one launch with an event pair when profiling is on.
 struct StageTimer {
     mipt_ctx* c;
@@ -240,6 +319,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         per_batch_max = std::max<size_t>(1, per_batch / 2);
     }
     const CameraRec cr = pack_camera(*cam);
+    const CullRects cull = screen_rects(sc, *cam, st->width, st->height);
     HIP_TRY(c, hipMemsetAsync(c->pb.totals, 0, sizeof(Totals), c->stream));
     c->ev_used = 0;
     c->spans.clear();
@@ -262,7 +342,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.lane_threshold = c->lane_threshold;
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
-        { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate_extend(c->stream, cr, sc->dev, bp, c->pb, sc->depth); }
+        { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate_extend(c->stream, cr, sc->dev, bp, c->pb, cull, sc->depth); }
         enqueue_bounces(c, sc, bp, st->bounces, 1);
         { StageTimer t(c, MIPT_STAGE_ACCUMULATE); launch_accumulate(c->stream, bp, c->pb, d_sum); }
         done += now;
@@ -286,6 +366,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         stats->sdf_noise_calls = t.sdf_noise_calls;
         stats->shade_evals = t.shade_near_evals;
         stats->shade_noise_calls = t.shade_noise_calls;
+        stats->primary_traced = t.primary_traced;
         stats->ms_device = ms;
         for (int k = 0; k < 6; ++k) {
             stats->stage_ms[k] = 0.0;
@@ -463,6 +544,16 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
         r.pad[0] = r.pad[1] = 0.0f;
     }
     const uint32_t n_analytic = static_cast<uint32_t>(boxes.size());
+    std::vector<std::array<float, 6>> analytic_boxes;
+    if (!boxes.empty()) {
+        std::array<float, 6> u{boxes[0].lo[0], boxes[0].lo[1], boxes[0].lo[2], boxes[0].hi[0], boxes[0].hi[1], boxes[0].hi[2]};
+        for (const BuildBox& b : boxes)
+            for (int a = 0; a < 3; ++a) {
+                u[a] = std::min(u[a], b.lo[a]);
+                u[3 + a] = std::max(u[3 + a], b.hi[a]);
+            }
+        analytic_boxes.push_back(u);
+    }
     BvhResult bvh = build_bvh(std::move(boxes));
 
     // Big craters of each crater ball (for_each_nearby_scattered_point at scale 2, PathTracerDemo.cpp:375-409):
@@ -564,6 +655,27 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     s->dev.craters = static_cast<const float*>(s->d_craters);
     s->dev.n_sdf = static_cast<uint32_t>(sdf.size());
     s->dev.n_prims = n;
+    {
+        const float big = std::numeric_limits<float>::max();
+        std::array<float, 6> all{big, big, big, -big, -big, -big};
+        auto grow = [](std::array<float, 6>& b, const float* lo, const float* hi) {
+            for (int a = 0; a < 3; ++a) {
+                b[a] = std::min(b[a], lo[a]);
+                b[3 + a] = std::max(b[3 + a], hi[a]);
+            }
+        };
+        if (!analytic_boxes.empty()) {
+            for (const auto& b : analytic_boxes) grow(all, b.data(), b.data() + 3);
+            s->cull_boxes.push_back(all);
+        }
+        if (sdf.size() <= 6) {
+            for (const SdfBox& b : sdf) s->cull_boxes.push_back({b.lo[0], b.lo[1], b.lo[2], b.hi[0], b.hi[1], b.hi[2]});
+        } else {
+            std::array<float, 6> m{big, big, big, -big, -big, -big};
+            for (const SdfBox& b : sdf) grow(m, b.lo, b.hi);
+            s->cull_boxes.push_back(m);
+        }
+    }
     s->n_nodes = static_cast<uint32_t>(bvh.nodes.size());
     s->n_analytic = n_analytic;
     s->n_sdf = static_cast<uint32_t>(sdf.size());
@@ -639,7 +751,7 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     c0.blur_radius = 0.0f;
     HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->pb.hit_key, 0xff, n * 8, c->stream));   // the fused kernel stores hits only
-    launch_generate_extend(c->stream, pack_camera(c0), sc->dev, bp, c->pb, sc->depth);
+    launch_generate_extend(c->stream, pack_camera(c0), sc->dev, bp, c->pb, screen_rects(sc, c0, width, height), sc->depth);
     if (sc->n_sdf) launch_sdf_march(c->stream, sc->dev, bp, c->pb, 0);
     std::vector<unsigned long long> keys(n);
     HIP_TRY(c, hipMemcpyAsync(keys.data(), c->pb.hit_key, n * 8, hipMemcpyDeviceToHost, c->stream));

@@ -36,8 +36,15 @@ struct BatchParams {
     uint64_t seed;
 };
 
+// Pixel rectangles (inclusive) outside of which no primary ray can reach anything: the screen bounds of
+// the scene's boxes.  Pixels outside all of them are not traced at all.
+struct CullRects {
+    int n;
+    int r[8][4];   // x0, y0, x1, y1
+};
+
 // generate + first extend fused; needs counters zeroed; fills queue[0] and the SDF queue of bounce 0
-void launch_generate_extend(hipStream_t, const CameraRec&, const SceneDev&, const BatchParams&, const PathBuffers&, int bvh_depth);
+void launch_generate_extend(hipStream_t, const CameraRec&, const SceneDev&, const BatchParams&, const PathBuffers&, const CullRects&, int bvh_depth);
 void launch_extend(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, int bvh_depth);
 // big-crater candidates of a crater ball: 12 floats per cell of the n^3 lattice cube at `base` (x-major)
 void launch_crater_cells(hipStream_t, const float off[3], const int base[3], int n, float* out);

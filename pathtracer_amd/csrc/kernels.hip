@@ -623,7 +623,7 @@ __device__ __forceinline__ bool xcd_cursor_take(XcdCursor& q, bool want, uint32_
 // scene that is ~10 % of the paths, the rest cost no memory traffic at all.
 // =============================================================================================
 template <int STACK, int CAP>
-__global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev sc, BatchParams bp, PathBuffers pb) {
+__global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev sc, BatchParams bp, PathBuffers pb, CullRects cull) {
     __shared__ int s_stack[STACK * 256];
     __shared__ uint32_t s_pend[2 * 4 * CAP];
     int* stack = s_stack + threadIdx.x;
@@ -640,9 +640,24 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
         box_hi = mk3(sc.sdf_boxes[0].hi[0], sc.sdf_boxes[0].hi[1], sc.sdf_boxes[0].hi[2]);
     }
     uint32_t n_sdf_rays = 0;
-    uint32_t s_next = in_image ? blockIdx.y : samples;   // this lane's next sample
-    uint32_t s_cur = blockIdx.y - gridDim.y;             // wave-uniform (wraps; advanced before use)
     const uint32_t words_per_sample = (bp.n_pix + 63u) / 64u;
+    // pixels from which nothing can be seen trace no rays
+    bool visible = false;
+    if (in_image)
+        for (int k = 0; k < cull.n; ++k)
+            visible = visible || (static_cast<int>(x) >= cull.r[k][0] && static_cast<int>(y) >= cull.r[k][1] && static_cast<int>(x) <= cull.r[k][2] &&
+                                  static_cast<int>(y) <= cull.r[k][3]);
+    if (!__ballot(visible)) {
+        // nothing for this wave to trace: its words of the live-path bitmap are all that is owed
+        if (__ballot(in_image)) {
+            const uint32_t word = (blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) >> 6;
+            for (uint32_t s = blockIdx.y + (threadIdx.x & 63u) * gridDim.y; s < samples; s += 64u * gridDim.y)
+                pb.live_bits[static_cast<size_t>(s) * words_per_sample + word] = 0ull;
+        }
+        return;
+    }
+    uint32_t s_next = visible ? blockIdx.y : samples;    // this lane's next sample
+    uint32_t s_cur = blockIdx.y - gridDim.y;             // wave-uniform (wraps; advanced before use)
     Trav t;
     t.busy = false;
     for (;;) {
@@ -687,6 +702,7 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
     pending_flush(live, &pb.counters[0].n_live, pb.queue[0]);
     pending_flush(to_sdf, &pb.counters[0].n_sdf, pb.sdf_queue);
     wave_add_total(&pb.totals->sdf_rays, n_sdf_rays);
+    wave_add_total(&pb.totals->primary_traced, visible ? (samples - blockIdx.y + gridDim.y - 1u) / gridDim.y : 0u);
 }
 
 // =============================================================================================
@@ -1249,16 +1265,17 @@ static inline uint32_t grid_for(size_t n, uint32_t cap = 256u * 32u) {
     return static_cast<uint32_t>(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
-void launch_generate_extend(hipStream_t st, const CameraRec& cam, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, int bvh_depth) {
+void launch_generate_extend(hipStream_t st, const CameraRec& cam, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, const CullRects& cull,
+                            int bvh_depth) {
     // one thread per pixel; enough sample stripes to fill the chip when the image is small
     const uint32_t bx = (bp.n_pix + 255u) / 256u, samples = bp.n_slots / bp.n_pix;
     const uint32_t by = std::max(1u, std::min(samples, (4096u + bx - 1u) / bx));
     const dim3 grid(bx, by), block(256);
     // (traversal stack, pending-queue capacity): LDS per block = STACK KiB + 8 CAP bytes, at most 64 KiB
-    if (bvh_depth <= 8) hipLaunchKernelGGL((k_generate_extend<8, 1024>), grid, block, 0, st, cam, sc, bp, pb);
-    else if (bvh_depth <= 24) hipLaunchKernelGGL((k_generate_extend<24, 512>), grid, block, 0, st, cam, sc, bp, pb);
-    else if (bvh_depth <= 40) hipLaunchKernelGGL((k_generate_extend<40, 256>), grid, block, 0, st, cam, sc, bp, pb);
-    else hipLaunchKernelGGL((k_generate_extend<60, 128>), grid, block, 0, st, cam, sc, bp, pb);
+    if (bvh_depth <= 8) hipLaunchKernelGGL((k_generate_extend<8, 1024>), grid, block, 0, st, cam, sc, bp, pb, cull);
+    else if (bvh_depth <= 24) hipLaunchKernelGGL((k_generate_extend<24, 512>), grid, block, 0, st, cam, sc, bp, pb, cull);
+    else if (bvh_depth <= 40) hipLaunchKernelGGL((k_generate_extend<40, 256>), grid, block, 0, st, cam, sc, bp, pb, cull);
+    else hipLaunchKernelGGL((k_generate_extend<60, 128>), grid, block, 0, st, cam, sc, bp, pb, cull);
 }
 
 void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, int bvh_depth) {

@@ -321,3 +321,26 @@ def test_fractal_object_is_exact(ctx, alg, oracle, golden):
     close = np.abs(want - got) <= 1e-4 * np.maximum(1.0, np.abs(want))
     assert close.all(axis=2).mean() >= 0.99
 
+
+
+def test_screen_culling_never_drops_a_hit(ctx, alg, oracle):
+    """Pixels outside the projected bounds of every object trace no ray.  Cameras at odd places -- inside
+    the scene's box, looking away from it, rotated, scaled, wide and narrow, objects straddling the plane
+    the rays start from -- must still give the oracle's primary-hit map exactly."""
+    flat = G.mixed_scene(alg)
+    osc = oracle.scene(flat)
+    ds = ctx.upload(flat)
+    r = np.random.RandomState(17)
+    n_hits = 0
+    for i in range(10):
+        rot = alg.affine_mul(S.linear_to_affine(alg.rotation("y", float(r.uniform(-3.1, 3.1)))),
+                             S.linear_to_affine(alg.rotation("x", float(r.uniform(-0.8, 0.8)))))
+        where = r.uniform(-3.0, 3.0, 3) if i % 2 else r.uniform(-12.0, 12.0, 3)
+        t = alg.affine_mul(S.translation(*[float(v) for v in where]), alg.affine_mul(rot, S.scale(float(r.choice([0.01, 0.3, 1.0])))))
+        cam = S.camera(t, aspect=float(r.choice([0.6, 1.0, 1.9])), fov=float(r.choice([8.0, 25.0, 60.0])), focal=10.0, blur=0.0)
+        want_prim, want_t = osc.primary_hits(cam, 64, 48)
+        got_prim, got_t = ctx.primary_hits(ds, cam, 64, 48)
+        assert np.array_equal(want_prim, got_prim), f"camera {i}: {np.sum(want_prim != got_prim)} pixels differ"
+        assert np.array_equal(want_t, got_t)
+        n_hits += int((want_prim >= 0).sum())
+    assert n_hits > 3000
