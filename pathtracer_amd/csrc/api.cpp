@@ -294,14 +294,18 @@ void enqueue_bounces(mipt_ctx* c, const mipt_scene* sc, const BatchParams& bp, u
         { StageTimer t(c, MIPT_STAGE_SHADE); launch_shade(c->stream, sc->dev, bp, c->pb, b, bounces); }
         if (sc->n_sdf) { StageTimer t(c, MIPT_STAGE_SHADE_SDF); launch_shade_sdf(c->stream, sc->dev, bp, c->pb, b, bounces); }
     }
-    launch_finish_batch(c->stream, c->pb, bounces, bp.n_slots);
+    // every real path casts a primary ray (tile padding does not)
+    const uint32_t primaries = bp.tiles_x ? bp.width * bp.height * (bp.n_slots / bp.n_pix) : bp.n_slots;
+    launch_finish_batch(c->stream, c->pb, bounces, primaries);
 }
 
 int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const mipt_settings* st, float* d_sum, mipt_stats* stats) {
     if (!c || !sc || !cam || !st || !d_sum) return MIPT_ERR_ARGUMENT;
     if (st->width < 2 || st->height < 2 || st->spp == 0 || st->bounces == 0) return MIPT_ERR_ARGUMENT;
     if (st->bounces > static_cast<uint32_t>(kMaxBounces)) return MIPT_ERR_TOO_LARGE;
-    const size_t n_pix = static_cast<size_t>(st->width) * st->height;
+    // pixel ids cover whole 8 x 8 tiles (BatchParams::tiles_x)
+    const uint32_t tiles_x = (st->width + 7u) / 8u, tiles_y = (st->height + 7u) / 8u;
+    const size_t n_pix = static_cast<size_t>(tiles_x) * tiles_y * 64;
     if (n_pix > (size_t(1) << 31)) return MIPT_ERR_TOO_LARGE;
     HIP_TRY(c, hipSetDevice(c->device));
     c->cancel.store(0);
@@ -337,6 +341,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.n_slots = static_cast<uint32_t>(n_pix * now);
         bp.width = st->width;
         bp.height = st->height;
+        bp.tiles_x = tiles_x;
         bp.first_sample = st->first_sample + done;
         bp.flags = st->flags;
         bp.lane_threshold = c->lane_threshold;
@@ -357,7 +362,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         HIP_TRY(c, hipMemcpy(&t, c->pb.totals, sizeof(t), hipMemcpyDeviceToHost));
         float ms = 0.0f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        stats->paths = static_cast<uint64_t>(n_pix) * done;
+        stats->paths = static_cast<uint64_t>(st->width) * st->height * done;
         stats->rays = t.rays;
         stats->sdf_rays = t.sdf_rays;
         stats->sdf_shades = t.sdf_shades;

@@ -27,9 +27,13 @@ struct PathBuffers {
 };
 
 struct BatchParams {
-    uint32_t n_slots;       // paths in this batch = n_pix * samples_in_batch
-    uint32_t n_pix;
+    uint32_t n_slots;       // path slots in this batch = n_pix * samples_in_batch
+    uint32_t n_pix;         // pixel ids per sample: width * height, or whole 8 x 8 tiles (see tiles_x)
     uint32_t width, height;
+    // 0: pixel id = y * width + x.  Otherwise the image is cut into 8 x 8 tiles, tiles_x per row, and
+    // pixel id = tile * 64 + (y & 7) * 8 + (x & 7): a wave's 64 paths are a square patch of the image (their
+    // rays meet the same few objects) and still occupy 8 full cache lines of every per-slot array.
+    uint32_t tiles_x;
     uint32_t first_sample;  // global sample index of sample 0 of this batch
     uint32_t flags;
     uint32_t lane_threshold;   // SDF near field: waiting lanes from which a wave evaluates one point per lane

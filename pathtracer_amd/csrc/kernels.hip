@@ -323,6 +323,19 @@ __device__ __forceinline__ f3 fractal_normal(f3 p) {   // deflectLocalRay :177-1
     return unit(mk3(g.x / delta, g.y / delta, g.z / delta));
 }
 
+// Pixel id -> image coordinates (BatchParams::tiles_x); false for ids past the image (tile padding).
+__device__ __forceinline__ bool pixel_of(const BatchParams& bp, uint32_t id, uint32_t& x, uint32_t& y) {
+    if (bp.tiles_x == 0u) {
+        y = id / bp.width;
+        x = id - y * bp.width;
+        return id < bp.n_pix;
+    }
+    const uint32_t tile = id >> 6, ty = tile / bp.tiles_x, tx = tile - ty * bp.tiles_x;
+    x = tx * 8u + (id & 7u);
+    y = ty * 8u + ((id >> 3) & 7u);
+    return id < bp.n_pix && x < bp.width && y < bp.height;
+}
+
 // =============================================================================================
 // Camera ray of sample `sample` of pixel (x, y): Renderer::doWork's sample set-up (src/Renderer.cpp:72-94)
 // + Camera::getViewRay (src/Camera.cpp:65-81).  (sx0, sy0) = (x / (w - 1), y / (h - 1)) is the same for
@@ -628,10 +641,11 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
     __shared__ uint32_t s_pend[2 * 4 * CAP];
     int* stack = s_stack + threadIdx.x;
     PendingQueue live{s_pend + (threadIdx.x >> 6) * CAP, CAP, 0u}, to_sdf{s_pend + (4u + (threadIdx.x >> 6)) * CAP, CAP, 0u};
-    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_image = pix < bp.n_pix;
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;   // pixel id; the slot of its sample s is s * n_pix + id
+    uint32_t x, y;
+    const bool in_image = pixel_of(bp, id, x, y);
+    const uint32_t pix = y * bp.width + x;                       // what the random numbers are keyed by
     const uint32_t samples = bp.n_slots / bp.n_pix;
-    const uint32_t y = pix / bp.width, x = pix - y * bp.width;
     const float sx0 = static_cast<float>(x) / static_cast<float>(bp.width - 1);
     const float sy0 = static_cast<float>(y) / static_cast<float>(bp.height - 1);
     f3 box_lo = mk3(0, 0, 0), box_hi = mk3(0, 0, 0);
@@ -665,7 +679,7 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
         if (!t.busy && s_next < samples) {
             f3 o, d;
             camera_ray(cam, bp, pix, bp.first_sample + s_next, sx0, sy0, o, d);
-            trav_begin(t, o, d, s_next * bp.n_pix + pix, sc.nodes != nullptr);
+            trav_begin(t, o, d, s_next * bp.n_pix + id, sc.nodes != nullptr);
             s_next += gridDim.y;
         }
         if (!__ballot(t.busy)) break;
@@ -693,7 +707,7 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
         // every wave and sample, so the bitmap needs no clearing)
         {
             const unsigned long long kept = __ballot(keep);
-            if ((threadIdx.x & 63u) == 0u) pb.live_bits[static_cast<size_t>(s_cur) * words_per_sample + (pix >> 6)] = kept;
+            if ((threadIdx.x & 63u) == 0u) pb.live_bits[static_cast<size_t>(s_cur) * words_per_sample + (id >> 6)] = kept;
         }
         pending_push(live, keep, t.slot, &pb.counters[0].n_live, pb.queue[0]);
         pending_push(to_sdf, wants_sdf, t.slot, &pb.counters[0].n_sdf, pb.sdf_queue);
@@ -1011,7 +1025,9 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
                         nrm = unit(cross(b - a, c - a));
                     }
                     const uint32_t s_local = slot / bp.n_pix;
-                    Rng rng(bp.seed, slot - s_local * bp.n_pix, bp.first_sample + s_local, 1u + bounce);
+                    uint32_t px, py;
+                    pixel_of(bp, slot - s_local * bp.n_pix, px, py);
+                    Rng rng(bp.seed, py * bp.width + px, bp.first_sample + s_local, 1u + bounce);
                     const Bounce b = deflect(sc.materials[pr.material], ld, nrm, rng);
                     alive = apply_bounce(pb, slot, pr, wp, b, bounce, max_bounces);
                 }
@@ -1087,7 +1103,9 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
                 nrm = unit(g);
             }
             const uint32_t s_local = slot / bp.n_pix;
-            Rng rng(bp.seed, slot - s_local * bp.n_pix, bp.first_sample + s_local, 1u + bounce);
+            uint32_t px, py;
+            pixel_of(bp, slot - s_local * bp.n_pix, px, py);
+            Rng rng(bp.seed, py * bp.width + px, bp.first_sample + s_local, 1u + bounce);
             const Bounce b = deflect(sc.materials[pr.material], ld, nrm, rng);
             alive = apply_bounce(pb, slot, pr, wp, b, bounce, max_bounces);
         }
@@ -1113,10 +1131,13 @@ __global__ void __launch_bounds__(256) k_accumulate(BatchParams bp, PathBuffers 
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t samples = bp.n_slots / bp.n_pix;
     const uint32_t words_per_sample = (bp.n_pix + 63u) / 64u;
-    for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < bp.n_pix; pix += stride) {
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < bp.n_pix; id += stride) {
+        uint32_t x, y;
+        if (!pixel_of(bp, id, x, y)) continue;
+        const uint32_t pix = y * bp.width + x;
         float r = frame[3 * pix], g = frame[3 * pix + 1], b = frame[3 * pix + 2];
-        const unsigned long long* bits = pb.live_bits + (pix >> 6);
-        const uint32_t bit = pix & 63u;
+        const unsigned long long* bits = pb.live_bits + (id >> 6);
+        const uint32_t bit = id & 63u;
         uint32_t s = 0;
         for (; s + 4u <= samples; s += 4u) {   // four bitmap words in flight
             const unsigned long long m0 = bits[static_cast<size_t>(s) * words_per_sample];
@@ -1127,7 +1148,7 @@ __global__ void __launch_bounds__(256) k_accumulate(BatchParams bp, PathBuffers 
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k)
                 if ((m[k] >> bit) & 1ull) {
-                    const float4 c = pb.rad[(s + k) * bp.n_pix + pix];
+                    const float4 c = pb.rad[(s + k) * bp.n_pix + id];
                     r += c.x;
                     g += c.y;
                     b += c.z;
@@ -1135,7 +1156,7 @@ __global__ void __launch_bounds__(256) k_accumulate(BatchParams bp, PathBuffers 
         }
         for (; s < samples; ++s)
             if ((bits[static_cast<size_t>(s) * words_per_sample] >> bit) & 1ull) {
-                const float4 c = pb.rad[s * bp.n_pix + pix];
+                const float4 c = pb.rad[s * bp.n_pix + id];
                 r += c.x;
                 g += c.y;
                 b += c.z;
