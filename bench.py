@@ -4,10 +4,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" is one full frame: every rank renders its share of the 1024 samples per pixel into a device
+One "step" is one full frame: every rank renders its block of the frame's samples per pixel into a device
 radiance-sum buffer, the buffers are summed with one RCCL all-reduce, scaled by 1/spp, tone-mapped on
-the GPU and copied to the host on rank 0.  Samples are addressed by their global index, so the frame
-is the same set of samples for every N (strong scaling: the total work per frame is fixed).
+the GPU and copied to the host on rank 0.  Samples are addressed by their global index.  By default the
+samples scale with the GPUs (--spp per GPU, N x spp per frame: weak scaling, the work per GPU is fixed);
+--scaling strong keeps the frame at --spp samples and divides them among the ranks.
 
 Rank 0 prints one JSON line.  `value` is Mpaths/s over the whole job; `roofline` prices the dominant
 kernel (the SDF march: bound by vector instruction issue, almost no memory traffic) from HIP events recorded around
@@ -45,7 +46,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
-    p.add_argument("--spp", type=int, default=1024)
+    p.add_argument("--spp", type=int, default=1024, help="samples per pixel: per GPU (weak scaling) or per frame (strong)")
+    p.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     p.add_argument("--bounces", type=int, default=8)
     p.add_argument("--scene", default="demo", choices=["demo", "random100k", "mixed20k"])
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,8 +93,9 @@ def main():
     upload_s = time.perf_counter() - t_up
     ctx.set_profiling(True)
 
-    # contiguous block of the global sample range per rank, remainder to the low ranks
-    my_first, my_spp = shard.sample_range(a.spp, world, rank)
+    # contiguous block of the frame's global sample range per rank, remainder to the low ranks
+    frame_spp = a.spp * world if a.scaling == "weak" else a.spp
+    my_first, my_spp = shard.sample_range(frame_spp, world, rank)
 
     d_sum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     d_ldr = torch.empty_like(d_sum)
@@ -105,7 +108,7 @@ def main():
         st = None
         if my_spp:
             st = ctx.render_accumulate(dscene, cam, W, H, a.bounces, my_spp, d_sum.data_ptr(), seed=2024, first_sample=my_first)
-        shard.reduce_frame(d_sum, a.spp, dist)   # RCCL all-reduce + 1/spp
+        shard.reduce_frame(d_sum, frame_spp, dist)   # RCCL all-reduce + 1/spp
         ctx.tonemap_device(1, d_sum.data_ptr(), d_ldr.data_ptr(), W, H)
         if rank == 0:
             h_out.copy_(d_ldr, non_blocking=True)
@@ -147,7 +150,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    total_paths = float(W) * H * a.spp * a.steps
+    total_paths = float(W) * H * frame_spp * a.steps
     ms_per_step = 1e3 * elapsed / a.steps
     out = {
         "metric": "Mpaths/s at 1080p (demo scene, 1024 spp, 8 bounces)" if (a.scene == "demo" and (W, H, a.spp) == (1920, 1080, 1024))
@@ -161,11 +164,11 @@ def main():
         "warmup": a.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": a.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{scene_label}, {W}x{H}, {a.spp} spp, {a.bounces} bounces, filmic tone map on GPU",
+        "config": {"workload": f"{scene_label}, {W}x{H}, {frame_spp} spp per frame ({my_spp} per GPU), {a.bounces} bounces, filmic tone map on GPU",
                    "primitives": flat.n_prims, "parallelism": f"spp-shard x{world} + RCCL all-reduce" if world > 1 else "single GPU",
                    "scene_upload_s": round(upload_s, 4)},
     }
