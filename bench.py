@@ -177,6 +177,10 @@ def main():
     stage_ms = agg.get("stage_ms", {})
     launches = agg.get("stage_launches", {})
     out["stage_ms_per_step"] = {k: round(v / a.steps, 3) for k, v in stage_ms.items()}
+    if "primary_traced" in agg and world == 1:
+        # closest-hit queries that cost a ray: primaries inside the objects' screen bounds plus every later cast
+        traced = agg["primary_traced"] + agg.get("rays", 0) - agg.get("paths", 0)
+        out["mrays_traced_per_s"] = traced / elapsed / 1e6
     out["work_per_step"] = {k: agg[k] // a.steps for k in ("paths", "rays", "sdf_rays", "sdf_shades", "sdf_far_evals", "sdf_near_evals",
                                                             "sdf_noise_calls", "shade_evals", "shade_noise_calls", "primary_traced") if k in agg}
     dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
