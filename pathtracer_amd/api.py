@@ -178,6 +178,13 @@ class Context:
         check(capi.dll().mipt_tonemap(self.h, kind, fp(img), fp(out), w, h), "mipt_tonemap")
         return out
 
+    def present_rgba8(self, sum_ptr, scale, tonemap, w, h):
+        """The demo's display step for a device accumulator: (h, w, 4) uint8."""
+        out = np.zeros((h, w, 4), np.uint8)
+        check(capi.dll().mipt_present_rgba8(self.h, C.c_void_p(sum_ptr), C.c_float(scale), int(tonemap),
+                                            out.ctypes.data_as(C.POINTER(C.c_uint8)), w, h), "mipt_present_rgba8")
+        return out
+
     def tonemap_device(self, kind, in_ptr, out_ptr, w, h):
         check(capi.dll().mipt_tonemap_device(self.h, kind, C.c_void_p(in_ptr), C.c_void_p(out_ptr), w, h),
               "mipt_tonemap_device")

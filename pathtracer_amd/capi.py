@@ -52,7 +52,7 @@ EXPORTS = [
     "mipt_init", "mipt_shutdown", "mipt_cancel", "mipt_last_hip_error", "mipt_set_profiling", "mipt_strerror", "mipt_scene_upload",
     "mipt_scene_free", "mipt_scene_info", "mipt_render", "mipt_render_accumulate", "mipt_scale_device",
     "mipt_primary_hits", "mipt_trace_rays", "mipt_tonemap", "mipt_tonemap_device", "mipt_affine_inverse",
-    "mipt_rotation", "mipt_affine_mul", "mipt_noise_transform", "mipt_world_bounds",
+    "mipt_rotation", "mipt_affine_mul", "mipt_noise_transform", "mipt_world_bounds", "mipt_present_rgba8",
 ]
 
 _dll = None
@@ -88,6 +88,7 @@ def dll():
         d.mipt_affine_mul.argtypes = [C.c_size_t, _f32p, _f32p, _f32p]
         d.mipt_noise_transform.argtypes = [_f32p, _f32p, _f32p]
         d.mipt_world_bounds.argtypes = [C.c_uint32, _f32p, _f32p, _f32p]
+        d.mipt_present_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.c_size_t]
         _dll = d
     return _dll
 

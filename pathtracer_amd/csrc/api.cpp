@@ -738,6 +738,33 @@ int mipt_scale_device(mipt_ctx* c, const float* in, float k, size_t n, float* ou
     return MIPT_OK;
 }
 
+int mipt_present_rgba8(mipt_ctx* c, const float* device_sum, float scale, int tonemap, uint8_t* out_rgba, size_t width, size_t height) {
+    if (!c || !device_sum || !out_rgba || width == 0 || height == 0 || tonemap < -1 || tonemap > 1) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n_pix = width * height, n = n_pix * 3;
+    // staging: scaled image, mapped image, packed pixels
+    const int rc = ensure_floats(c, &c->stage, &c->stage_cap, 2 * n + n_pix);
+    if (rc != MIPT_OK) return rc;
+    float* scaled = c->stage;
+    float* mapped = c->stage + n;
+    uint32_t* packed = reinterpret_cast<uint32_t*>(c->stage + 2 * n);
+    launch_scale(c->stream, device_sum, scale, n, scaled);
+    const float* shown = scaled;
+    if (tonemap == 1) {
+        launch_tonemap_filmic(c->stream, scaled, mapped, n);
+        shown = mapped;
+    } else if (tonemap == 0) {
+        launch_tonemap_reinhard(c->stream, scaled, mapped, width, height, c->tm_scratch, reinhard_scratch_floats());
+        shown = mapped;
+    }
+    launch_pack_rgba8(c->stream, shown, n_pix, packed);
+    HIP_TRY(c, hipMemcpyAsync(out_rgba, packed, n_pix * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return MIPT_OK;
+}
+
 int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, uint32_t width, uint32_t height, int32_t* out_prim, float* out_t) {
     if (!c || !sc || !cam || !out_prim || !out_t || width < 2 || height < 2) return MIPT_ERR_ARGUMENT;
     std::lock_guard<std::mutex> lock(c->mutex);

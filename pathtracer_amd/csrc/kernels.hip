@@ -1172,6 +1172,21 @@ __global__ void __launch_bounds__(256) k_scale(const float* in, float k, size_t 
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i] * k;
 }
 
+// copyToSFImage's conversion (PathTracerDemo.cpp:524-545): clamp to [0, 1], times 255, truncate; bytes R, G, B, A = 255
+__global__ void __launch_bounds__(256) k_pack_rgba8(const float* in, size_t n_pix, uint32_t* out) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
+        uint32_t px = 0xff000000u;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float v = in[3 * i + ch];
+            const float cl = v < 0.0f ? 0.0f : (1.0f < v ? 1.0f : v);   // std::clamp; a NaN shows as 0
+            px |= static_cast<uint32_t>(cl == cl ? cl * 255.0f : 0.0f) << (8 * ch);
+        }
+        out[i] = px;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_load_rays(const float* pos, const float* dir, uint32_t n, PathBuffers pb) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1335,6 +1350,10 @@ void launch_accumulate(hipStream_t st, const BatchParams& bp, const PathBuffers&
 
 void launch_scale(hipStream_t st, const float* in, float k, size_t n, float* out) {
     hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(256), 0, st, in, k, n, out);
+}
+
+void launch_pack_rgba8(hipStream_t st, const float* in, size_t n_pix, uint32_t* out) {
+    hipLaunchKernelGGL(k_pack_rgba8, dim3(grid_for(n_pix)), dim3(256), 0, st, in, n_pix, out);
 }
 
 void launch_load_rays(hipStream_t st, const float* pos, const float* dir, uint32_t n, const PathBuffers& pb) {

@@ -344,3 +344,27 @@ def test_screen_culling_never_drops_a_hit(ctx, alg, oracle):
         assert np.array_equal(want_t, got_t)
         n_hits += int((want_prim >= 0).sum())
     assert n_hits > 3000
+
+
+def test_present_rgba8_is_the_demo_display_step(ctx, alg):
+    """mipt_present_rgba8 = scaleImage(acc, 1/count), optional tone map, copyToSFImage (clamp, * 255,
+    truncate; PathTracerDemo.cpp:524-545, 963-971) for an accumulator that stays on the device."""
+    import torch
+    flat, cam = S.cornell_scene(alg), S.cornell_camera(alg)
+    ds = ctx.upload(flat)
+    w, h = 72, 40
+    acc = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for frame in range(3):   # three progressive frames of 4 samples each, accumulated on the device
+        ctx.render_accumulate(ds, cam, w, h, 6, 4, acc.data_ptr(), seed=1, first_sample=4 * frame)
+    scale = np.float32(1.0 / 12.0)
+    mean = acc.cpu().numpy() * scale
+    want = (np.clip(mean, 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
+    got = ctx.present_rgba8(acc.data_ptr(), float(scale), -1, w, h)
+    assert np.array_equal(got[..., :3], want) and np.all(got[..., 3] == 255)
+    assert want.max() == 255 and 0 < (want > 0).mean() < 1
+    mapped = ctx.tonemap(1, mean)
+    got = ctx.present_rgba8(acc.data_ptr(), float(scale), 1, w, h)
+    assert np.array_equal(got[..., :3], (np.clip(mapped, 0.0, 1.0) * np.float32(255.0)).astype(np.uint8))
+    full, _ = ctx.render(ds, cam, w, h, 6, 12, seed=1)
+    assert np.allclose(mean, full, rtol=1e-5, atol=1e-6)
