@@ -49,7 +49,7 @@ def parse():
     p.add_argument("--spp", type=int, default=1024, help="samples per pixel: per GPU (weak scaling) or per frame (strong)")
     p.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     p.add_argument("--bounces", type=int, default=8)
-    p.add_argument("--scene", default="demo", choices=["demo", "random100k", "mixed20k"])
+    p.add_argument("--scene", default="demo", choices=["demo", "random100k", "random1m", "mixed20k"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-spp", type=int, default=64, help="samples per pixel of the CPU baseline's bounded sample")
     return p.parse_args()
@@ -61,6 +61,9 @@ def build_scene(name, alg, aspect):
     if name == "random100k":
         return (S.random_scene(alg, 100_000, seed=7), S.random_scene_camera(alg, aspect),
                 "100k random spheres/boxes, diffuse+specular")
+    if name == "random1m":
+        return (S.random_scene(alg, 1_000_000, seed=7, radius_scale=0.46), S.random_scene_camera(alg, aspect),
+                "1M random spheres/boxes, diffuse+specular")
     return (S.random_scene(alg, 20_000, seed=9, radius_scale=2.0, glass_mirror_mix=True), S.random_scene_camera(alg, aspect),
             "20k mirrors/glass/emitters")
 

@@ -368,3 +368,21 @@ def test_present_rgba8_is_the_demo_display_step(ctx, alg):
     assert np.array_equal(got[..., :3], (np.clip(mapped, 0.0, 1.0) * np.float32(255.0)).astype(np.uint8))
     full, _ = ctx.render(ds, cam, w, h, 6, 12, seed=1)
     assert np.allclose(mean, full, rtol=1e-5, atol=1e-6)
+
+
+def test_config4_1m_primitives_first_hits(ctx, alg, oracle):
+    """Config 4's scene (1,000,000 primitives, radii scaled by 0.46): closest hits of 512 camera rays
+    against the brute-force scan over every primitive."""
+    flat = S.random_scene(alg, 1_000_000, seed=7, radius_scale=0.46)
+    cam = S.random_scene_camera(alg)
+    r = np.random.RandomState(13)
+    sx, sy = r.uniform(0, 1, 512).astype(np.float32), r.uniform(0, 1, 512).astype(np.float32)
+    d, o = oracle.camera_rays(cam, sx, sy, rng_mode=1, seed=1)
+    ds = ctx.upload(flat)
+    info = ds.info()
+    assert info["analytic"] == 1_000_000 and 20 <= info["depth"] <= 60
+    _, prim, t = ctx.trace_rays(ds, o, d, 1, seed=1, first_hit=True)
+    wp, wt, _ = oracle.scene(flat).closest_hit(o, d)
+    assert np.array_equal(wp, prim)
+    assert np.array_equal(wt[wp >= 0], t[wp >= 0])
+    assert (wp >= 0).mean() > 0.2
