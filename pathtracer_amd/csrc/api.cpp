@@ -477,6 +477,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     if (d->n_prims == 0 || !d->kind || !d->fwd || !d->inv || !d->params || !d->material || !d->materials || d->n_materials == 0)
         return MIPT_ERR_ARGUMENT;
     if (d->n_prims > (1u << 30)) return MIPT_ERR_TOO_LARGE;
+    std::lock_guard<std::mutex> lock(c->mutex);   // the crater tables are computed on the context's stream
     HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t n = d->n_prims;
     std::vector<PrimRec> prims(n);
