@@ -27,6 +27,8 @@ struct mipt_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::atomic<int> cancel{0};
+    volatile uint32_t* cancel_host = nullptr;   // pinned, mapped: the kernels read it through cancel_dev
+    const volatile uint32_t* cancel_dev = nullptr;
     int last_hip = 0;
     std::mutex mutex;   // render calls are serialised, as Renderer::render is (src/Renderer.cpp:144)
 
@@ -125,6 +127,7 @@ int ensure_slots(mipt_ctx* c, size_t slots, size_t words) {
     const size_t o_cnt = take(sizeof(BounceCounters) * (kMaxBounces + 1));
     const size_t o_tot = take(sizeof(Totals));
     const size_t o_bits = take(words * 8);
+    const size_t o_latch = take(sizeof(uint32_t));
     void* base = nullptr;
     const hipError_t e = hipMalloc(&base, off);
     if (e != hipSuccess) {
@@ -147,6 +150,8 @@ int ensure_slots(mipt_ctx* c, size_t slots, size_t words) {
     c->pb.counters = reinterpret_cast<BounceCounters*>(b + o_cnt);
     c->pb.totals = reinterpret_cast<Totals*>(b + o_tot);
     c->pb.live_bits = reinterpret_cast<unsigned long long*>(b + o_bits);
+    c->pb.cancel = c->cancel_dev;
+    c->pb.cancel_latch = reinterpret_cast<uint32_t*>(b + o_latch);
     c->bits_cap = words;
     return MIPT_OK;
 }
@@ -289,6 +294,7 @@ struct StageTimer {
 void enqueue_bounces(mipt_ctx* c, const mipt_scene* sc, const BatchParams& bp, uint32_t bounces, int first_done) {
     for (uint32_t b = 0; b < bounces; ++b) {
         const int done = b == 0 ? first_done : 0;
+        if (b > 0) launch_latch_cancel(c->stream, c->pb);
         if (done < 1) { StageTimer t(c, MIPT_STAGE_EXTEND); launch_extend(c->stream, sc->dev, bp, c->pb, b, sc->depth); }
         if (sc->n_sdf && done < 2) { StageTimer t(c, MIPT_STAGE_SDF_MARCH); launch_sdf_march(c->stream, sc->dev, bp, c->pb, b); }
         { StageTimer t(c, MIPT_STAGE_SHADE); launch_shade(c->stream, sc->dev, bp, c->pb, b, bounces); }
@@ -309,6 +315,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
     if (n_pix > (size_t(1) << 31)) return MIPT_ERR_TOO_LARGE;
     HIP_TRY(c, hipSetDevice(c->device));
     c->cancel.store(0);
+    if (c->cancel_host) *c->cancel_host = 0u;
     // equal batches, as few as the memory budget allows; on an allocation failure try smaller ones
     size_t per_batch_max = std::max<size_t>(1, batch_path_budget(c) / n_pix);
     uint32_t per_batch = 0;
@@ -347,8 +354,10 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.lane_threshold = c->lane_threshold;
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
+        launch_latch_cancel(c->stream, c->pb);
         { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate_extend(c->stream, cr, sc->dev, bp, c->pb, cull, sc->depth); }
         enqueue_bounces(c, sc, bp, st->bounces, 1);
+        launch_latch_cancel(c->stream, c->pb);
         { StageTimer t(c, MIPT_STAGE_ACCUMULATE); launch_accumulate(c->stream, bp, c->pb, d_sum); }
         done += now;
         // keep at most a couple of batches queued so that cancellation stays responsive
@@ -357,6 +366,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
+    if (c->cancel.load(std::memory_order_relaxed)) status = MIPT_ERR_CANCELLED;   // possibly in the middle of the last batch
     if (stats) {
         Totals t{};
         HIP_TRY(c, hipMemcpy(&t, c->pb.totals, sizeof(t), hipMemcpyDeviceToHost));
@@ -419,6 +429,18 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
         mipt_shutdown(c);
         return MIPT_ERR_NO_DEVICE;
     }
+    {
+        void* host = nullptr;
+        void* dev = nullptr;
+        if (hipHostMalloc(&host, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) {
+            if (host) (void)hipHostFree(host);
+            mipt_shutdown(c);
+            return MIPT_ERR_NO_DEVICE;
+        }
+        c->cancel_host = static_cast<volatile uint32_t*>(host);
+        *c->cancel_host = 0u;
+        c->cancel_dev = static_cast<const volatile uint32_t*>(dev);
+    }
     if (const char* e = std::getenv("MIPT_LANE_THRESHOLD")) {
         const long v = std::atol(e);
         if (v >= 1 && v <= 65) c->lane_threshold = static_cast<uint32_t>(v);
@@ -435,6 +457,7 @@ void mipt_shutdown(mipt_ctx* c) {
     if (c->frame) (void)hipFree(c->frame);
     if (c->stage) (void)hipFree(c->stage);
     if (c->tm_scratch) (void)hipFree(c->tm_scratch);
+    if (c->cancel_host) (void)hipHostFree(const_cast<uint32_t*>(c->cancel_host));
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -445,6 +468,7 @@ void mipt_shutdown(mipt_ctx* c) {
 int mipt_cancel(mipt_ctx* c) {
     if (!c) return MIPT_ERR_ARGUMENT;
     c->cancel.store(1, std::memory_order_relaxed);
+    if (c->cancel_host) *c->cancel_host = 1u;
     return MIPT_OK;
 }
 
@@ -774,6 +798,8 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     if (n > (size_t(1) << 28)) return MIPT_ERR_TOO_LARGE;
     int rc = ensure_slots(c, n, (n + 63) / 64);
     if (rc != MIPT_OK) return rc;
+    c->cancel.store(0);
+    *c->cancel_host = 0u;
     BatchParams bp{};
     bp.n_pix = bp.n_slots = static_cast<uint32_t>(n);
     bp.width = width;
@@ -784,6 +810,7 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     c0.blur_radius = 0.0f;
     HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->pb.hit_key, 0xff, n * 8, c->stream));   // the fused kernel stores hits only
+    launch_latch_cancel(c->stream, c->pb);
     launch_generate_extend(c->stream, pack_camera(c0), sc->dev, bp, c->pb, screen_rects(sc, c0, width, height), sc->depth);
     if (sc->n_sdf) launch_sdf_march(c->stream, sc->dev, bp, c->pb, 0);
     std::vector<unsigned long long> keys(n);
@@ -812,6 +839,8 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = ensure_slots(c, n, 1);
     if (rc != MIPT_OK) return rc;
+    c->cancel.store(0);
+    *c->cancel_host = 0u;
     rc = ensure_floats(c, &c->stage, &c->stage_cap, static_cast<size_t>(n) * 6);
     if (rc != MIPT_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->stage, pos, static_cast<size_t>(n) * 12, hipMemcpyHostToDevice, c->stream));
@@ -823,6 +852,7 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     bp.lane_threshold = c->lane_threshold;
     bp.seed = seed;
     HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
+    launch_latch_cancel(c->stream, c->pb);
     launch_load_rays(c->stream, c->stage, c->stage + static_cast<size_t>(n) * 3, n, c->pb);
     std::vector<unsigned long long> keys;
     if (out_first_prim || out_first_t) {

@@ -24,6 +24,12 @@ struct PathBuffers {
     // one bit per slot, set for the paths whose primary ray hit something or reached an SDF box (only
     // those ever carry radiance); sample s of pixel p is bit p & 63 of word s * ceil(n_pix / 64) + p / 64
     unsigned long long* live_bits;
+    // cancellation: `cancel` points at a word in pinned host memory that mipt_cancel sets.  A one-thread
+    // kernel copies it into `cancel_latch` (device memory) before every bounce and before the accumulation;
+    // every kernel returns at once when the latch is set, so a cancelled frame drains within one bounce, and
+    // all threads of the accumulation agree on whether the batch enters the frame.
+    const volatile uint32_t* cancel;
+    uint32_t* cancel_latch;
 };
 
 struct BatchParams {
@@ -57,6 +63,7 @@ void launch_shade(hipStream_t, const SceneDev&, const BatchParams&, const PathBu
 void launch_shade_sdf(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, uint32_t max_bounces);
 void launch_finish_batch(hipStream_t, const PathBuffers&, uint32_t bounces, uint32_t n_slots);
 // frame[pix] += sum over the batch's samples, in sample order (the `acc +=` of src/Renderer.cpp:97-99)
+void launch_latch_cancel(hipStream_t, const PathBuffers&);
 void launch_accumulate(hipStream_t, const BatchParams&, const PathBuffers&, float* frame_sum);
 void launch_scale(hipStream_t, const float* in, float k, size_t n, float* out);
 void launch_pack_rgba8(hipStream_t, const float* in_rgb, size_t n_pix, uint32_t* out_rgba);

@@ -637,6 +637,7 @@ __device__ __forceinline__ bool xcd_cursor_take(XcdCursor& q, bool want, uint32_
 // =============================================================================================
 template <int STACK, int CAP>
 __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev sc, BatchParams bp, PathBuffers pb, CullRects cull) {
+    if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
     __shared__ int s_stack[STACK * 256];
     __shared__ uint32_t s_pend[2 * 4 * CAP];
     int* stack = s_stack + threadIdx.x;
@@ -725,6 +726,7 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
 // =============================================================================================
 template <int STACK>
 __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
+    if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
     __shared__ int s_stack[STACK * 256];
     constexpr uint32_t kCap = 128;
     __shared__ uint32_t s_pend[4 * kCap];
@@ -811,6 +813,7 @@ __device__ __forceinline__ int march_step(March& m, float d2) {
 }
 
 __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
+    if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
     const uint32_t n = pb.counters[bounce].n_sdf;
     if (n == 0) return;
     uint32_t* head = &pb.counters[bounce].sdf_head;
@@ -987,6 +990,7 @@ __device__ __forceinline__ bool apply_bounce(const PathBuffers& pb, uint32_t slo
 }
 
 __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce, uint32_t max_bounces) {
+    if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
     constexpr uint32_t kCap = 1024;
     __shared__ uint32_t s_pend[2 * 4 * kCap];
     PendingQueue survivors{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u}, sdf_hits{s_pend + (4u + (threadIdx.x >> 6)) * kCap, kCap, 0u};
@@ -1045,6 +1049,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
 // the four points of one hit, so a wave shades 16 hits per round; the quad's first lane then deflects
 // the path.  Hits are dealt to waves round-robin so that a short queue spreads over all waves.
 __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce, uint32_t max_bounces) {
+    if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
     const uint32_t n = pb.counters[bounce].n_sdf_shade;
     uint32_t* next_queue = pb.queue[(bounce + 1) & 1];
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -1125,9 +1130,12 @@ __global__ void k_finish_batch(PathBuffers pb, uint32_t bounces, uint32_t n_slot
     pb.totals->rays += rays;
 }
 
+__global__ void k_latch_cancel(PathBuffers pb) { *pb.cancel_latch = pb.cancel ? *pb.cancel : 0u; }
+
 // frame[pix] += sample 0 + sample 1 + ... of this batch, sequentially in sample order.  Only the paths
 // marked in the batch's bitmap carry radiance; the others would add exactly zero and are not read.
 __global__ void __launch_bounds__(256) k_accumulate(BatchParams bp, PathBuffers pb, float* frame) {
+    if (*pb.cancel_latch) return;   // cancelled: this batch stays out of the frame
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t samples = bp.n_slots / bp.n_pix;
     const uint32_t words_per_sample = (bp.n_pix + 63u) / 64u;
@@ -1343,6 +1351,8 @@ void launch_shade_sdf(hipStream_t st, const SceneDev& sc, const BatchParams& bp,
 void launch_finish_batch(hipStream_t st, const PathBuffers& pb, uint32_t bounces, uint32_t n_slots) {
     hipLaunchKernelGGL(k_finish_batch, dim3(1), dim3(1), 0, st, pb, bounces, n_slots);
 }
+
+void launch_latch_cancel(hipStream_t st, const PathBuffers& pb) { hipLaunchKernelGGL(k_latch_cancel, dim3(1), dim3(1), 0, st, pb); }
 
 void launch_accumulate(hipStream_t st, const BatchParams& bp, const PathBuffers& pb, float* frame) {
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(bp.n_pix)), dim3(256), 0, st, bp, pb, frame);

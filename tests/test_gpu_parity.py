@@ -386,3 +386,39 @@ def test_config4_1m_primitives_first_hits(ctx, alg, oracle):
     assert np.array_equal(wp, prim)
     assert np.array_equal(wt[wp >= 0], t[wp >= 0])
     assert (wp >= 0).mean() > 0.2
+
+
+def test_cancel_drains_a_running_frame(alg):
+    """Renderer::cancelRender from another thread (src/Renderer.cpp:174-176): the kernels of the frame that
+    have not started yet return at once, so render comes back long before the frame would have finished."""
+    import threading
+    import time
+    from pathtracer_amd import capi
+    c = api.Context()
+    flat, cam = S.random_scene(alg, 100_000, seed=7), S.random_scene_camera(alg, 16.0 / 9.0)
+    ds = c.upload(flat)
+    c.render(ds, cam, 64, 36, 8, 1)                     # warm up (allocations, code objects)
+    t0 = time.perf_counter()
+    c.render(ds, cam, 1920, 1080, 8, 128, seed=1)       # the frame, uncancelled
+    full_s = time.perf_counter() - t0
+    result = {}
+
+    def work():
+        t1 = time.perf_counter()
+        try:
+            c.render(ds, cam, 1920, 1080, 8, 128, seed=1)
+            result["status"] = 0
+        except api.MiptError as e:
+            result["status"] = e.status
+        result["seconds"] = time.perf_counter() - t1
+
+    th = threading.Thread(target=work)
+    th.start()
+    time.sleep(0.05)
+    c.cancel()
+    th.join()
+    assert result["status"] == capi.ERR_CANCELLED
+    assert result["seconds"] < 0.6 * full_s, (result, full_s)
+    img, st = c.render(ds, cam, 64, 36, 8, 2)            # the context is usable afterwards
+    assert st["paths"] == 64 * 36 * 2 and img.max() > 0
+    c.close()
