@@ -124,7 +124,8 @@ int  mipt_init(int device, void* stream, mipt_ctx** out);
 /* Renderer::~Renderer / stopThreadPool (src/Renderer.cpp:14-16, 37-52). */
 void mipt_shutdown(mipt_ctx*);
 /* Renderer::cancelRender (src/Renderer.cpp:174-176): callable from any thread, lock-free.  The
- * running render call stops at the next sample batch and returns MIPT_ERR_CANCELLED. */
+ * running render call drains (the kernels it still has queued return at once, within one bounce)
+ * and returns MIPT_ERR_CANCELLED; the sample batch in flight stays out of the result. */
 int  mipt_cancel(mipt_ctx*);
 int  mipt_last_hip_error(const mipt_ctx*);
 /* Measurement aid (no counterpart in the reference): when on, render calls bracket every kernel launch
