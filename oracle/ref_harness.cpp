@@ -90,6 +90,9 @@ std::unique_ptr<Object> make_object(uint32_t kind, const float* p, const BasicMa
             o->material = m;
             return o;
         }
+#ifdef DEMO_SDF_INC
+        case 5: return std::make_unique<RoughBoxObject>(Rectangle(Vec(p[0], p[1], p[2])), m);
+#endif
     }
     return nullptr;
 }

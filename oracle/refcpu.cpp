@@ -401,6 +401,47 @@ struct SdfCounters {
     uint64_t evals = 0, near_evals = 0;
 };
 
+// voronoi() :118-154 with its default arguments (scatter 1, identity transform: the inverse of the identity
+// and the products with it return their operand unchanged).
+struct Voronoi {
+    float sqr, next_sqr;
+    uint32_t hash;
+};
+Voronoi voronoi(V3 location) {
+    Voronoi v{std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), 0u};
+    scattered_points(location, 1.0f, 2, [&](V3 c, uint32_t h) {
+        const float d = norm_sq(location - c);
+        if (d < v.sqr) {
+            v.next_sqr = std::min(v.sqr, v.next_sqr);
+            v.sqr = d;
+            v.hash = h;
+        } else {
+            v.next_sqr = std::min(d, v.next_sqr);
+        }
+    });
+    return v;
+}
+
+float rect_sdf(V3 half, V3 p) {   // Rectangle::signedDistance src/Geometry.cpp:66-75
+    const float dx = std::abs(p.x) - half.x, dy = std::abs(p.y) - half.y, dz = std::abs(p.z) - half.z;
+    return norm(v3(std::max(dx, 0.0f), std::max(dy, 0.0f), std::max(dz, 0.0f))) + std::min(std::max(std::max(dx, dy), dz), 0.0f);
+}
+
+// RoughBoxObject :228-270: a box eroded by noise, cut by the walls of a voronoi foam.
+float roughbox_sdf(V3 half, const Aff& NT, V3 pos) {   // :237-246
+    const float voronoi_scale = 0.03723f;
+    const Voronoi v = voronoi(div(pos, voronoi_scale));
+    return std::max(rect_sdf(half, pos) - 0.3f + 2.0f * fbm_noise(NT, 1.0f * pos),
+                    (std::sqrt(v.sqr) - std::sqrt(v.next_sqr) + 0.1f) * voronoi_scale);
+}
+// deflectLocalRay :248-259: the cell of a coarser foam colours the surface.
+V3 roughbox_albedo(V3 pos) {
+    const Voronoi v = voronoi(div(pos, 0.2f));
+    return v3(static_cast<float>(0.6f + 0.4f * static_cast<float>(v.hash & 0xff) / 256.0),
+              static_cast<float>(0.3f + 0.5f * static_cast<float>((v.hash >> 8) & 0xff) / 256.0),
+              static_cast<float>(0.1f + 0.4f * static_cast<float>((v.hash >> 16) & 0xff) / 256.0));
+}
+
 float craterball_sdf(V3 off, const Aff& NT, V3 pos, SdfCounters* cnt) {   // :361-466
     if (cnt) cnt->evals++;
     const float sdf_sphere = norm(pos) - 0.5f;
@@ -559,6 +600,10 @@ Box world_bbox(uint32_t kind, const Aff& T, const float* p);
 std::optional<V3> hit_local(uint32_t kind, const float* p, const Aff& noise, const Aff& fwd, const Ray& r, SdfCounters* cnt) {
     switch (kind) {
         case ORC_FRACTAL: return fractal_march(r, world_bbox(kind, fwd, p));
+        case ORC_ROUGHBOX: {
+            const V3 half = v3(p[0], p[1], p[2]);
+            return sdf_march(r, Box{v3(0, 0, 0), 2.0f * half}, [&](V3 q) { return roughbox_sdf(half, noise, q); });   // localBoundingBox :261-266
+        }
         case ORC_SPHERE: return hit_sphere(r, p[0]);                                   // src/Object.cpp:116-118
         case ORC_BOX: return hit_rect(r, v3(p[0], p[1], p[2]));                        // :141-143
         case ORC_TRIANGLE: return hit_triangle(r, v3(p[0], p[1], p[2]), v3(p[3], p[4], p[5]), v3(p[6], p[7], p[8]));   // :88-90
@@ -583,6 +628,10 @@ V3 normal_local(uint32_t kind, const float* p, const Aff& noise, V3 pos, SdfCoun
             return sdf_normal(pos, [&](V3 q) { return craterball_sdf(off, noise, q, cnt); });
         }
         case ORC_FRACTAL: return fractal_normal(pos);
+        case ORC_ROUGHBOX: {
+            const V3 half = v3(p[0], p[1], p[2]);
+            return sdf_normal(pos, [&](V3 q) { return roughbox_sdf(half, noise, q); });
+        }
     }
     return v3(0, 0, 1);
 }
@@ -599,6 +648,7 @@ Box local_bbox(uint32_t kind, const float* p) {   // *::getLocalBoundingBox src/
             return box_from_corners(lo, hi);
         }
         case ORC_FRACTAL: return Box{v3(0, 0, 0), v3(2.0f, 2.0f, 2.0f)};   // src/Object.cpp:191-196
+        case ORC_ROUGHBOX: return Box{v3(0, 0, 0), 2.0f * v3(p[0], p[1], p[2])};
         default: return kCraterBox;
     }
 }
@@ -631,7 +681,9 @@ template <class Rng>
 Bounce deflect_object(const SceneData& s, const Prim& o, const Ray& r, Rng& rng, SdfCounters* cnt) {
     const Ray local{xform_vec(o.inv, r.dir), xform_pos(o.inv, r.pos)};
     const V3 n = normal_local(o.kind, o.p, s.noise, local.pos, cnt);
-    Bounce b = deflect(s.mats[o.material], local.dir, n, rng);
+    Material m = s.mats[o.material];
+    if (o.kind == ORC_ROUGHBOX) m.albedo = roughbox_albedo(local.pos);   // `m.setReflectedAbsorption(...)` :253-257
+    Bounce b = deflect(m, local.dir, n, rng);
     b.dir = xform_vec(o.fwd, b.dir);
     return b;
 }

@@ -14,7 +14,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-SPHERE, BOX, TRIANGLE, CRATERBALL, FRACTAL = 0, 1, 2, 3, 4
+SPHERE, BOX, TRIANGLE, CRATERBALL, FRACTAL, ROUGHBOX = 0, 1, 2, 3, 4, 5
 
 IDENTITY12 = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float32)
 
@@ -91,6 +91,10 @@ class SceneBuilder:
 
     def craterball(self, offset, mat, fwd=None):
         return self._add(CRATERBALL, list(offset), mat, fwd)
+
+    def roughbox(self, half, mat, fwd=None):
+        """The demo's RoughBoxObject (PathTracerDemo.cpp:228-270); needs the scene's noise transform."""
+        return self._add(ROUGHBOX, list(half), mat, fwd)
 
     def fractal(self, mat, fwd=None):
         """FractalObject (include/Object.hpp:179-192): no parameters beyond its material."""

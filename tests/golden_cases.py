@@ -93,6 +93,14 @@ def make_inputs():
     o[:30] = r.uniform(-1.9, 1.9, (30, 3))
     inp["fr_ray_pos"], inp["fr_ray_dir"] = o.astype(np.float32), dd.astype(np.float32)
 
+    # --- RoughBoxObject (local frame): rays at the eroded box, SDF samples around its surface
+    r = _rs(8)
+    inp["rb_half"] = np.array([0.5, 0.4, 0.6], np.float32)
+    o = _unit(r.normal(size=(240, 3))) * r.uniform(2.2, 4.0, (240, 1))
+    dd = _unit(r.uniform(-0.6, 0.6, (240, 3)) - o) * r.choice([0.5, 1.0, 1.6], (240, 1))
+    o[:16] = r.uniform(-0.9, 0.9, (16, 3)) * [1.0, 0.8, 1.2]      # origins inside the bounding box
+    inp["rb_ray_pos"], inp["rb_ray_dir"] = o.astype(np.float32), dd.astype(np.float32)
+
     # --- camera
     g = np.linspace(0, 1, 9, dtype=np.float32)
     sx, sy = np.meshgrid(g, g)
@@ -182,6 +190,22 @@ def fractal_scene(alg):
     return b.build()
 
 
+def roughbox_scene(alg, noise):
+    """The demo's RoughBoxObject, rotated and scaled, with a floor and a light."""
+    b = S.SceneBuilder(alg, noise)
+    t = alg.affine_mul(S.translation(0.2, 0.1, 0.3),
+                       alg.affine_mul(S.linear_to_affine(alg.rotation("y", 0.7)),
+                                      alg.affine_mul(S.linear_to_affine(alg.rotation("x", 0.3)), S.scale(1.3))))
+    b.roughbox((0.5, 0.4, 0.6), S.material(diffuse=0.9, specular=0.1, sharpness=0.5), t)
+    b.box((6.0, 0.1, 6.0), S.material(diffuse=1.0, specular=0.0, albedo=(0.7, 0.7, 0.7)), S.translation(0.0, 2.4, 0.0))
+    b.box((2.0, 0.05, 2.0), S.material(diffuse=1.0, specular=0.0, emitted=(12.0, 11.0, 10.0)), S.translation(0.0, -5.0, 0.0))
+    return b.build()
+
+
+def roughbox_camera(alg, aspect=1.0):
+    return S.camera(S.translation(0.0, 0.0, -8.0), aspect=aspect, fov=14.0, focal=10.0, blur=0.0)
+
+
 def fractal_camera(alg, aspect=1.0):
     """Close enough for the lattice to fill a good part of the frame, and outside the object's world box
     as the object's own frame sees it."""
@@ -238,6 +262,7 @@ class HostApiBackend(RefBackend):
     def __init__(self, host, noise, gpu):
         self.api = host
         self.gpu = gpu
+        self.has_demo_classes = host.has("ref_noise")
         self.noise = np.asarray(noise, np.float32)
         host.set_noise(self.noise)
 
@@ -394,6 +419,20 @@ def evaluate(be, inp, heavy=True):
     out["fr_primary_prim"], out["fr_primary_t"] = sc.primary_hits(fcam, 64, 64)
     out["fr_trace"] = be.trace(sc, o[:150] * 0.9, d[:150], 6, 7)
     out["fr_render"] = be.render(sc, fcam, 32, 32, 6, 2, 26)
+
+    # RoughBoxObject (a class of the demo program: only builds that carry the demo's SDF block have it)
+    if getattr(be, "has_demo_classes", True):
+        rp = np.concatenate([inp["rb_half"], np.zeros(6, np.float32)])
+        hit, pos = be.hit_local(5, rp, inp["rb_ray_pos"], inp["rb_ray_dir"])
+        out["rb_hit"], out["rb_hitpos"] = hit, pos
+        out["rb_normal"] = be.normal_local(5, rp, pos[hit][:48])
+        rs = roughbox_scene(alg, be.noise)
+        out["rb_bbox"] = api.world_bbox(5, rs.fwd[0], rp)
+        sc = be.scene(rs)
+        rcam = roughbox_camera(alg)
+        out["rb_primary_prim"], out["rb_primary_t"] = sc.primary_hits(rcam, 40, 40)
+        out["rb_trace"] = be.trace(sc, o[:80] * 0.9, d[:80], 5, 8)
+        out["rb_render"] = be.render(sc, rcam, 24, 24, 5, 2, 27)
 
     if heavy:
         dm = S.demo_scene(alg, be.noise)
