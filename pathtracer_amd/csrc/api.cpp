@@ -509,14 +509,15 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     std::vector<BuildBox> boxes;
     std::vector<SdfBox> sdf;
     boxes.reserve(n);
-    bool any_tri = false, any_sdf = false;
+    bool any_tri = false, any_sdf = false /* crater balls */, any_plain = false /* SDF kinds evaluated one point per lane */;
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t k = d->kind[i];
-        if (k > MIPT_FRACTAL || d->material[i] >= d->n_materials) return MIPT_ERR_ARGUMENT;
+        if (k > MIPT_ROUGHBOX || d->material[i] >= d->n_materials) return MIPT_ERR_ARGUMENT;
         any_tri |= (k == MIPT_TRIANGLE);
         any_sdf |= (k == MIPT_CRATERBALL);
+        any_plain |= (k == MIPT_ROUGHBOX);
     }
-    if (any_sdf && !d->noise_transform) return MIPT_ERR_ARGUMENT;
+    if ((any_sdf || any_plain) && !d->noise_transform) return MIPT_ERR_ARGUMENT;
     if (any_tri) tri_c.assign(static_cast<size_t>(3) * n, 0.0f);
     for (uint32_t i = 0; i < n; ++i) {
         PrimRec& r = prims[i];
@@ -529,6 +530,11 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
         if (r.kind == MIPT_TRIANGLE) std::memcpy(&tri_c[3 * static_cast<size_t>(i)], p + 6, sizeof(float) * 3);
         float lo[3], hi[3];
         if (!world_bounds(r.kind, r.fwd, p, lo, hi)) return MIPT_ERR_ARGUMENT;
+        if (r.kind == MIPT_ROUGHBOX) {
+            // the foam's lattice coordinates (position / 0.03723) must stay exact 24-bit integers
+            for (int a = 0; a < 3; ++a)
+                if (!(p[a] >= 0.0f && p[a] < 7.0e4f)) return MIPT_ERR_ARGUMENT;
+        }
         if (r.kind == MIPT_FRACTAL) {
             // FractalObject marches from where its LOCAL ray enters its WORLD bounding box
             // (src/Object.cpp:161): keep that box as AxisAlignedBox(Pos, Pos) forms it (src/Geometry.cpp:348-358)
@@ -545,7 +551,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
             lo[a] -= pad;
             hi[a] += pad;
         }
-        if (r.kind == MIPT_CRATERBALL || r.kind == MIPT_FRACTAL) {
+        if (r.kind >= MIPT_CRATERBALL) {
             SdfBox s{};
             std::memcpy(s.lo, lo, sizeof(lo));
             std::memcpy(s.hi, hi, sizeof(hi));
@@ -599,6 +605,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
         std::vector<float> cells(kCells * 12);
         for (const SdfBox& sb : sdf) {
             PrimRec& r = prims[sb.prim];
+            if (r.kind != MIPT_CRATERBALL) continue;
             int base[3];
             for (int a = 0; a < 3; ++a) {
                 if (!(std::fabs(r.p[a]) < 4.0e6f)) {   // lattice coordinates must stay exact 24-bit integers
@@ -647,9 +654,10 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     // repeats; octave i therefore samples q_i = A_i p + b_i with A_0 = L, b_0 = t, A_i = 1.1 L A_{i-1},
     // b_i = 1.1 L b_{i-1} + t.  Composed in double, stored as float (13 per octave: A row-major, b + 0.25,
     // weight), so the 8 octaves of one call can be evaluated side by side.
-    float oct[8 * 13] = {};
-    if (any_sdf) {
+    float oct[8 * 13 + 12] = {};   // the raw transform follows the octave table
+    if (any_sdf || any_plain) {
         const float* nt = d->noise_transform;
+        std::memcpy(oct + 8 * 13, nt, 12 * sizeof(float));
         double A[9], bb[3];
         for (int i = 0; i < 9; ++i) A[i] = nt[i];
         for (int i = 0; i < 3; ++i) bb[i] = nt[9 + i];
@@ -682,6 +690,8 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     s->dev.nodes = static_cast<const BvhNode*>(s->d_nodes);
     s->dev.sdf_boxes = static_cast<const SdfBox*>(s->d_sdf);
     s->dev.noise_oct = static_cast<const float*>(s->d_oct);
+    s->dev.noise_raw = s->d_oct ? static_cast<const float*>(s->d_oct) + 8 * 13 : nullptr;
+    s->dev.plain_sdf = any_plain ? 1u : 0u;
     s->dev.craters = static_cast<const float*>(s->d_craters);
     s->dev.n_sdf = static_cast<uint32_t>(sdf.size());
     s->dev.n_prims = n;

@@ -9,7 +9,7 @@ namespace mipt {
 struct alignas(128) PrimRec {
     float inv[12];      // world -> local  (Object::m_inverseTransformation)
     float fwd[12];      // local -> world  (Object::m_transformation)
-    float p[6];         // sphere {r}; box {hx,hy,hz}; crater ball {offset, first crater, craters}; triangle {a, b} (c in tri_c)
+    float p[6];         // sphere {r}; box {hx,hy,hz}; crater ball {offset, first crater, craters}; rough box {halfSize}; fractal {world box}; triangle {a, b} (c in tri_c)
     uint32_t kind;
     uint32_t material;
 };
@@ -64,6 +64,9 @@ struct SceneDev {
     // big craters of every crater ball: 12 floats per crater {cell.xyz, size, on_sphere.xyz, t, age bits, 1/(5 size), -, -};
     // a ball's records start at record PrimRec::p[3] and number PrimRec::p[4] (both uint32 bit patterns)
     const float* craters;
+    // the raw noise transform (Linear row-major, then the translation), read by the SDF kinds that run noise() octave by octave
+    const float* noise_raw;
+    uint32_t plain_sdf;            // the scene holds SDF kinds evaluated one point per lane (RoughBoxObject)
 };
 
 // Per-bounce queue counters of one sample batch, zeroed once per batch.

@@ -776,6 +776,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
 }
 
 #include "craterball.h"
+#include "demo_sdf.h"
 
 // =============================================================================================
 // sdf_march: SDFObjectCRTP::hitLocalRay (include/Object.hpp:135-167) as a per-lane state machine.
@@ -794,7 +795,8 @@ struct March {
 // One iteration of the reference's loop body given the SDF value d2 at m.p.  Returns 0 to continue,
 // 1 for a hit (m.p is the hit), 2 for a miss.  The reference evaluates the SDF once before the loop
 // and again, at the same point, in iteration 0; both values are d2 here.
-__device__ __forceinline__ int march_step(March& m, float d2) {
+// `box` is the half extent of the object's localBoundingBox (centred on the origin).
+__device__ __forceinline__ int march_step(March& m, float d2, f3 box) {
     if (m.first) {
         m.d = d2;
         m.sign = d2 > 0.0f;
@@ -807,11 +809,14 @@ __device__ __forceinline__ int march_step(March& m, float d2) {
         m.d = d2;
         if (fabsf(m.d) < 1e-4f) return 1;
         m.p = m.p + fabsf(m.d) * m.dir;
-        if (!inside_rect(m.p, mk3(1.0f, 1.0f, 1.0f))) return 2;   // CraterBallObject::localBoundingBox :474-479
+        if (!inside_rect(m.p, box)) return 2;
     }
     return ++m.iter >= 256u ? 2 : 0;
 }
 
+// PLAIN: the scene holds SDF kinds that are evaluated one point per lane (RoughBoxObject); scenes
+// without them run the instantiation that does not carry that code.
+template <bool PLAIN>
 __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
     if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
     const uint32_t n = pb.counters[bounce].n_sdf;
@@ -824,7 +829,8 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv_d = mk3(0, 0, 0), off = mk3(0, 0, 0), best_pos = mk3(0, 0, 0);
     float inv_len2 = 0.0f, limit = 0.0f;
     unsigned long long best = kMissKey;
-    bool improved = false;
+    bool improved = false, plain = false;
+    const f3 ball_box = mk3(1.0f, 1.0f, 1.0f);   // CraterBallObject::localBoundingBox PathTracerDemo.cpp:474-479
     uint32_t c_far = 0, c_near = 0, c_noise = 0;
     __shared__ __attribute__((aligned(16))) float s_coop[4 * kNearLdsFloats];
     const uint32_t lane = __lane_id();
@@ -904,9 +910,14 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
                 off = mk3(pr->p[0], pr->p[1], pr->p[2]);
                 crater_base = __float_as_uint(pr->p[3]);
                 crater_count = __float_as_uint(pr->p[4]);
+                f3 box = ball_box;
+                if (PLAIN) {
+                    plain = pr->kind == 5u;
+                    if (plain) box = mk3(2.0f * off.x, 2.0f * off.y, 2.0f * off.z);   // RoughBoxObject::localBoundingBox :261-266 (p[0..2] = halfSize)
+                }
                 bool ok = true;
                 f3 p0 = lo;
-                if (!inside_rect(lo, mk3(1.0f, 1.0f, 1.0f))) ok = hit_rect(lo, ld, mk3(1.0f, 1.0f, 1.0f), p0);   // intersect(ray, bb), box centred at 0
+                if (!inside_rect(lo, box)) ok = hit_rect(lo, ld, box, p0);   // intersect(ray, bb), box centred at 0
                 if (ok) {
                     m.p = p0;
                     m.dir = ld;
@@ -923,20 +934,24 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
         // (3) far-field steps are a handful of flops: take them until a near-field evaluation is due
         int result = 0;
         float s = 0.0f;
-        if (state == MARCH) {
+        if (PLAIN && state == MARCH && plain) {
+            // one step of a lane-evaluated object (`off` holds the box's halfSize)
+            ++c_near;
+            result = march_step(m, roughbox_sdf(off, sc.noise_raw, m.p), mk3(2.0f * off.x, 2.0f * off.y, 2.0f * off.z));
+        } else if (state == MARCH) {
             for (;;) {
                 s = norm(m.p) - 0.5f;
                 if (!(static_cast<double>(s) > 0.1)) break;   // `sdf_sphere > 0.1` compares against a double literal
                 ++c_far;
-                result = march_step(m, s);
+                result = march_step(m, s, ball_box);
                 if (result) break;
             }
         }
-        // (4) near-field evaluations for the lanes that need one
-        const bool wants = state == MARCH && result == 0;
+        // (4) near-field evaluations for the crater-ball lanes that need one
+        const bool wants = state == MARCH && result == 0 && !(PLAIN && plain);
         float d2 = 0.0f;
         wave_near(sc.craters, cl, lds, lane, bp.lane_threshold, wants, m.p, off, s, crater_base, crater_count, d2, c_near, c_noise);
-        if (wants) result = march_step(m, d2);
+        if (wants) result = march_step(m, d2, ball_box);
         // (5) finished marches fold into the ray's best hit and move on to the next primitive
         if (state == MARCH && result != 0) {
             if (result == 1) {
@@ -1048,6 +1063,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
 // include/Object.hpp:118-132): at the hit and at +delta along x, y, z.  The four lanes of a quad take
 // the four points of one hit, so a wave shades 16 hits per round; the quad's first lane then deflects
 // the path.  Hits are dealt to waves round-robin so that a short queue spreads over all waves.
+template <bool PLAIN>
 __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce, uint32_t max_bounces) {
     if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
     const uint32_t n = pb.counters[bounce].n_sdf_shade;
@@ -1073,7 +1089,7 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
         PrimRegs pr;
         f3 wp = mk3(0, 0, 0), ld = mk3(0, 0, 0), p = mk3(0, 0, 0), off = mk3(0, 0, 0), local_hit = mk3(0, 0, 0);
         float s = 0.0f;
-        bool fractal = false;
+        bool fractal = false, plain = false;
         if (valid) {
             slot = pb.sdf_shade_queue[i];
             const uint32_t prim = static_cast<uint32_t>(pb.hit_key[slot] & 0xffffffffu);
@@ -1083,6 +1099,7 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
             ld = lin_mul(pr.inv, d);
             const f3 lp = aff_pos(pr.inv, wp);
             fractal = pr.kind == 4u;
+            if (PLAIN) plain = pr.kind == 5u;
             local_hit = lp;
             if (!fractal) {
                 off = mk3(pr.p[0], pr.p[1], pr.p[2]);
@@ -1094,8 +1111,9 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
             }
         }
         // the far field returns the sphere distance itself (`sdf_sphere > 0.1` compares against a double literal)
-        const bool wants = valid && !fractal && !(static_cast<double>(s) > 0.1);
+        const bool wants = valid && !fractal && !(PLAIN && plain) && !(static_cast<double>(s) > 0.1);
         float v = s;
+        if (PLAIN && plain) v = roughbox_sdf(off, sc.noise_raw, p);   // each lane of the quad evaluates its own point
         wave_near(sc.craters, cl, lds, lane, bp.lane_threshold, wants, p, off, s, crater_base, crater_count, v, c_near, c_noise);
         const float v0 = dpp_f<0x00>(0.0f, v), v1 = dpp_f<0x55>(0.0f, v), v2 = dpp_f<0xAA>(0.0f, v), v3 = dpp_f<0xFF>(0.0f, v);   // quad broadcasts
         bool alive = false;
@@ -1111,7 +1129,17 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
             uint32_t px, py;
             pixel_of(bp, slot - s_local * bp.n_pix, px, py);
             Rng rng(bp.seed, py * bp.width + px, bp.first_sample + s_local, 1u + bounce);
-            const Bounce b = deflect(sc.materials[pr.material], ld, nrm, rng);
+            Bounce b;
+            if (PLAIN && plain) {   // `m.setReflectedAbsorption(...)` PathTracerDemo.cpp:253-257
+                MaterialRec mat = sc.materials[pr.material];
+                const f3 a = roughbox_albedo(local_hit);
+                mat.albedo[0] = a.x;
+                mat.albedo[1] = a.y;
+                mat.albedo[2] = a.z;
+                b = deflect(mat, ld, nrm, rng);
+            } else {
+                b = deflect(sc.materials[pr.material], ld, nrm, rng);
+            }
             alive = apply_bounce(pb, slot, pr, wp, b, bounce, max_bounces);
         }
         pending_push(survivors, alive, slot, &pb.counters[bounce + 1].n_live, next_queue);
@@ -1337,7 +1365,8 @@ void launch_crater_cells(hipStream_t st, const float off[3], const int base[3], 
 
 void launch_sdf_march(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce) {
     // persistent waves: enough blocks to fill the chip a few times over, every wave drains the queue
-    hipLaunchKernelGGL(k_sdf_march, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce);
+    if (sc.plain_sdf) hipLaunchKernelGGL(k_sdf_march<true>, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce);
+    else hipLaunchKernelGGL(k_sdf_march<false>, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce);
 }
 
 void launch_shade(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, uint32_t max_bounces) {
@@ -1345,7 +1374,8 @@ void launch_shade(hipStream_t st, const SceneDev& sc, const BatchParams& bp, con
 }
 
 void launch_shade_sdf(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, uint32_t max_bounces) {
-    hipLaunchKernelGGL(k_shade_sdf, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce, max_bounces);
+    if (sc.plain_sdf) hipLaunchKernelGGL(k_shade_sdf<true>, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce, max_bounces);
+    else hipLaunchKernelGGL(k_shade_sdf<false>, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce, max_bounces);
 }
 
 void launch_finish_batch(hipStream_t st, const PathBuffers& pb, uint32_t bounces, uint32_t n_slots) {

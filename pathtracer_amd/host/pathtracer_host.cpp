@@ -421,16 +421,19 @@ float FractalObject::signedDistance(const Pos& p) const noexcept {
 }
 
 // ================================================================================================
-// the demo's CraterBallObject, recognised without its cooperation
+// the demo's CraterBallObject and RoughBoxObject, recognised without their cooperation
 // ================================================================================================
 bool mipt_host::describeKnownDemoSdf(const char* name, std::size_t derived_size, std::size_t base_size, const void* object, DevicePrimitive& out) noexcept {
-    // Itanium mangling of a global class: <length><name>.  The class has exactly one data member, a Vec,
-    // laid out directly behind the SDFObjectCRTP base (PathTracerDemo.cpp:481-482).
-    if (std::strcmp(name, "16CraterBallObject") != 0) return false;
+    // Itanium mangling of a global class: <length><name>.  Either class has exactly one data member laid out
+    // directly behind the SDFObjectCRTP base: CraterBallObject a Vec (PathTracerDemo.cpp:481-482),
+    // RoughBoxObject a Rectangle, which is its halfSize Vec (PathTracerDemo.cpp:268-269, include/Geometry.hpp).
+    static_assert(sizeof(Rectangle) == sizeof(Vec), "Rectangle is its halfSize");
+    const bool ball = std::strcmp(name, "16CraterBallObject") == 0, box = std::strcmp(name, "14RoughBoxObject") == 0;
+    if (!ball && !box) return false;
     if (derived_size < base_size + sizeof(Vec) || derived_size > base_size + sizeof(Vec) + 8) return false;
     float off[3];
     std::memcpy(off, static_cast<const char*>(object) + base_size, sizeof(off));
-    out.kind = MIPT_CRATERBALL;
+    out.kind = ball ? MIPT_CRATERBALL : MIPT_ROUGHBOX;
     out.params[0] = off[0];
     out.params[1] = off[1];
     out.params[2] = off[2];
@@ -647,12 +650,12 @@ mipt_scene* sync_scene(const Scene& scene) {
         if (d.kind < 0 || !d.material) {
             std::fprintf(stderr,
                          "pathtracer: object %zu (type %s) has no device counterpart: supported are SphereObject, BoxObject, TriangleObject, FractalObject, the demo's "
-                         "CraterBallObject and SDF classes that specialise mipt_host::DeviceSdf.\n",
+                         "CraterBallObject and RoughBoxObject and SDF classes that specialise mipt_host::DeviceSdf.\n",
                          i, d.type_name);
             std::abort();
         }
         kind[i] = static_cast<uint32_t>(d.kind);
-        any_sdf |= d.kind == MIPT_CRATERBALL;
+        any_sdf |= d.kind == MIPT_CRATERBALL || d.kind == MIPT_ROUGHBOX;
         if (d.noise && !own_noise) own_noise = d.noise;
         material[i] = static_cast<uint32_t>(i);
         affine_to(objs[i]->transformation(), &fwd[12 * i]);
@@ -665,7 +668,7 @@ mipt_scene* sync_scene(const Scene& scene) {
         std::memcpy(noise, own_noise, sizeof(noise));   // one noise transform per scene: the first CraterBall's
     } else if (any_sdf) {
         if (!&noiseTransform) {
-            std::fprintf(stderr, "pathtracer: the scene holds a crater ball but the program defines no noiseTransform()\n");
+            std::fprintf(stderr, "pathtracer: the scene holds a crater ball or a rough box but the program defines no noiseTransform()\n");
             std::abort();
         }
         affine_to(noiseTransform(), noise);

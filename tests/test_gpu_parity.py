@@ -323,6 +323,76 @@ def test_fractal_object_is_exact(ctx, alg, oracle, golden):
 
 
 
+def test_roughbox_object_is_exact(ctx, alg, oracle, golden):
+    """The demo's RoughBoxObject (PathTracerDemo.cpp:228-270): voronoi foam, noise() octave by octave and the
+    SDFObjectCRTP march are evaluated one point per lane in the reference's order of operations, so primary
+    hits equal the reference's fixture and the oracle bit for bit; the per-hit albedo (hash of the foam
+    cell under the hit) enters the traced radiance."""
+    flat, cam = G.roughbox_scene(alg, golden["noise12"]), G.roughbox_camera(alg)
+    ds = ctx.upload(flat)
+    assert ds.info()["sdf"] == 1
+    got_prim, got_t = ctx.primary_hits(ds, cam, 40, 40)
+    assert np.array_equal(golden["rb_primary_prim"], got_prim)
+    assert np.array_equal(golden["rb_primary_t"], got_t)
+    assert (got_prim == 0).sum() > 150
+    osc = oracle.scene(flat)
+    want_prim, want_t = osc.primary_hits(cam, 96, 96)
+    got_prim, got_t = ctx.primary_hits(ds, cam, 96, 96)
+    assert np.array_equal(want_prim, got_prim)
+    assert np.array_equal(want_t, got_t)
+    # traced rays aimed at the box, from all around (and some from inside its bounding box)
+    r = np.random.RandomState(14)
+    c = np.array([0.2, 0.1, 0.3])
+    o = (c + _unit(r.normal(size=(2000, 3))) * r.uniform(0.9, 5.0, (2000, 1))).astype(np.float32)
+    d = _unit(c + r.uniform(-0.7, 0.7, (2000, 3)) - o)
+    want = osc.trace(o, d, 5, rng_mode=1, seed=33)
+    got, prim, t = ctx.trace_rays(ds, o, d, 5, seed=33, first_hit=True)
+    wp, wt, _ = osc.closest_hit(o, d)
+    assert np.array_equal(wp, prim)
+    assert np.array_equal(wt[wp >= 0], t[wp >= 0])
+    assert (wp == 0).sum() > 500
+    close = np.all(np.abs(want - got) <= 1e-4 * np.maximum(1.0, np.abs(want)), axis=1)
+    assert close.mean() >= 0.995, f"only {close.mean():.4f} of paths agree"
+    # image with shared random numbers
+    want, wstats = osc.render(cam, 40, 40, 5, 4, rng_mode=1, seed=9, threads=0, full_width=True)
+    got, gstats = ctx.render(ds, cam, 40, 40, 5, 4, seed=9)
+    assert abs(gstats["rays"] - wstats["rays"]) <= 2e-3 * wstats["rays"]
+    close = np.abs(want - got) <= 1e-4 * np.maximum(1.0, np.abs(want))
+    assert close.all(axis=2).mean() >= 0.99
+
+
+def test_every_sdf_kind_in_one_scene(ctx, alg, oracle, golden):
+    """A crater ball, a rough box and a fractal lattice share one scene (and one march kernel) with analytic
+    primitives: the exact kinds keep their bit-exact hits, the crater ball its march tolerance."""
+    b = S.SceneBuilder(alg, golden["noise12"])
+    m = S.material(diffuse=0.9, specular=0.1, sharpness=0.5)
+    b.craterball((0.3, 0.6, 0.1), m, alg.affine_mul(S.translation(-1.6, 0.0, 0.0), S.scale(1.4)))
+    b.roughbox((0.35, 0.3, 0.4), m, S.translation(1.5, 0.0, 0.2))
+    b.fractal(m, alg.affine_mul(S.translation(0.0, -1.9, 0.5), S.scale(0.45)))
+    b.box((6.0, 0.1, 6.0), S.material(diffuse=1.0, specular=0.0, albedo=(0.7, 0.7, 0.7)), S.translation(0.0, 1.2, 0.0))
+    b.sphere(0.4, S.material(diffuse=0.0, specular=1.0, sharpness=1.0), S.translation(0.0, 0.3, -0.6))
+    b.box((2.0, 0.05, 2.0), S.material(diffuse=1.0, specular=0.0, emitted=(12.0, 11.0, 10.0)), S.translation(0.0, -5.0, 0.0))
+    flat = b.build()
+    cam = S.camera(S.translation(0.0, -0.3, -9.0), aspect=1.0, fov=14.0, focal=10.0, blur=0.0)
+    ds = ctx.upload(flat)
+    assert ds.info()["sdf"] == 3
+    osc = oracle.scene(flat)
+    want_prim, want_t = osc.primary_hits(cam, 96, 96)
+    got_prim, got_t = ctx.primary_hits(ds, cam, 96, 96)
+    for k in range(6):
+        assert (want_prim == k).sum() > 40, k
+    ball = (want_prim == 0) | (got_prim == 0)
+    assert np.array_equal(want_prim[~ball], got_prim[~ball])
+    assert np.array_equal(want_t[~ball], got_t[~ball])
+    assert (want_prim != got_prim).mean() <= 0.005
+    both = (want_prim == 0) & (got_prim == 0)
+    assert np.abs(want_t[both] - got_t[both]).max() <= 1e-3   # ball scaled by 1.4, t in units of the ray direction
+    want, wstats = osc.render(cam, 48, 48, 5, 4, rng_mode=1, seed=5, threads=0, full_width=True)
+    got, gstats = ctx.render(ds, cam, 48, 48, 5, 4, seed=5)
+    assert abs(gstats["rays"] - wstats["rays"]) <= 5e-3 * wstats["rays"]
+    assert abs(got.mean() - want.mean()) <= 0.03 * want.mean()
+
+
 def test_screen_culling_never_drops_a_hit(ctx, alg, oracle):
     """Pixels outside the projected bounds of every object trace no ray.  Cameras at odd places -- inside
     the scene's box, looking away from it, rotated, scaled, wide and narrow, objects straddling the plane
