@@ -1,6 +1,6 @@
 // The demo's signed-distance objects that are evaluated one point per lane, in the reference's own
 // order of operations (PathTracerDemo.cpp:26-154, 228-270).  Included by kernels.hip after
-// craterball.h (whose hashed lattice cell it shares).  Everything here is +, -, *, /, sqrt, floor,
+// craterball.h (whose hashed lattice cell it shares).  Everything here is +, -, *, sqrt, floor,
 // min and max with contraction off, so the values are the reference's bit for bit.
 #pragma once
 
@@ -58,7 +58,7 @@ __device__ __forceinline__ float rect_sdf(f3 half, f3 p) {   // Rectangle::signe
 // RoughBoxObject::signedDistance :237-246: a box eroded by noise, cut by the walls of a voronoi foam.
 __device__ __forceinline__ float roughbox_sdf(f3 half, const float* T, f3 pos) {
     const float voronoi_scale = 0.03723f;
-    const VoronoiHit v = voronoi_cells(mk3(pos.x / voronoi_scale, pos.y / voronoi_scale, pos.z / voronoi_scale));
+    const VoronoiHit v = voronoi_cells(pos * (1.0f / voronoi_scale));   // Vec / float multiplies by the reciprocal (src/LinearAlgebra.cpp:278-281)
     return fmaxf(rect_sdf(half, pos) - 0.3f + 2.0f * noise_seq(T, mk3(1.0f * pos.x, 1.0f * pos.y, 1.0f * pos.z)),
                  (sqrtf(v.sqr) - sqrtf(v.next_sqr) + 0.1f) * voronoi_scale);
 }
@@ -67,7 +67,7 @@ __device__ __forceinline__ float roughbox_sdf(f3 half, const float* T, f3 pos) {
 // forms each channel through double (`/ 256.0`); the float sum rounds the same exact value once.
 __device__ __forceinline__ f3 roughbox_albedo(f3 pos) {
     const float voronoi_scale = 0.2f;
-    const VoronoiHit v = voronoi_cells(mk3(pos.x / voronoi_scale, pos.y / voronoi_scale, pos.z / voronoi_scale));
+    const VoronoiHit v = voronoi_cells(pos * (1.0f / voronoi_scale));
     return mk3(0.6f + 0.4f * static_cast<float>(v.hash & 0xffu) / 256.0f,
                0.3f + 0.5f * static_cast<float>((v.hash >> 8) & 0xffu) / 256.0f,
                0.1f + 0.4f * static_cast<float>((v.hash >> 16) & 0xffu) / 256.0f);

@@ -320,7 +320,7 @@ __device__ __forceinline__ f3 fractal_normal(f3 p) {   // deflectLocalRay :177-1
     const float delta = 1e-3f;
     const f3 dx = mk3(delta, 0.0f, 0.0f), dy = mk3(0.0f, delta, 0.0f), dz = mk3(0.0f, 0.0f, delta);
     const f3 g = mk3(fractal_sdf(p + dx) - fractal_sdf(p - dx), fractal_sdf(p + dy) - fractal_sdf(p - dy), fractal_sdf(p + dz) - fractal_sdf(p - dz));
-    return unit(mk3(g.x / delta, g.y / delta, g.z / delta));
+    return unit(g * (1.0f / delta));   // Vec / float multiplies by the reciprocal (src/LinearAlgebra.cpp:278-281)
 }
 
 // Pixel id -> image coordinates (BatchParams::tiles_x); false for ids past the image (tile padding).
