@@ -92,6 +92,8 @@ std::unique_ptr<Object> make_object(uint32_t kind, const float* p, const BasicMa
         }
 #ifdef DEMO_SDF_INC
         case 5: return std::make_unique<RoughBoxObject>(Rectangle(Vec(p[0], p[1], p[2])), m);
+        case 6: return std::make_unique<RoughSphereObject>(Sphere(p[0]), m, m);
+        case 7: return std::make_unique<WeirdWallObject>(m);
 #endif
     }
     return nullptr;

@@ -435,13 +435,79 @@ float roughbox_sdf(V3 half, const Aff& NT, V3 pos) {   // :237-246
                     (std::sqrt(v.sqr) - std::sqrt(v.next_sqr) + 0.1f) * voronoi_scale);
 }
 // deflectLocalRay :248-259: the cell of a coarser foam colours the surface.
-V3 roughbox_albedo(V3 pos) {
-    const Voronoi v = voronoi(div(pos, 0.2f));
+V3 foam_albedo(V3 pos, float voronoi_scale) {   // the same expression colours WeirdWallObject :333-339 (scale 0.018347)
+    const Voronoi v = voronoi(div(pos, voronoi_scale));
     return v3(static_cast<float>(0.6f + 0.4f * static_cast<float>(v.hash & 0xff) / 256.0),
               static_cast<float>(0.3f + 0.5f * static_cast<float>((v.hash >> 8) & 0xff) / 256.0),
               static_cast<float>(0.1f + 0.4f * static_cast<float>((v.hash >> 16) & 0xff) / 256.0));
 }
 
+// voronoi() :118-154 in general: scatter and a Linear that shears the distance metric.
+Voronoi voronoi(V3 location, float scatter, const Lin& transform) {
+    Lin inv;
+    inverse(transform, inv);   // `*transform.inverse()`
+    location = mul(inv, location);
+    Voronoi v{std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), 0u};
+    scattered_points(location, scatter, 2, [&](V3 c, uint32_t h) {
+        const float d = norm_sq(mul(transform, location - c));
+        if (d < v.sqr) {
+            v.next_sqr = std::min(v.sqr, v.next_sqr);
+            v.sqr = d;
+            v.hash = h;
+        } else {
+            v.next_sqr = std::min(d, v.next_sqr);
+        }
+    });
+    return v;
+}
+
+inline float smin(float a, float b, float k) {   // :72-76
+    return -std::log2(std::exp2(-k * a) + std::exp2(-k * b)) / k;
+}
+
+// RoughSphereObject :156-226: a sphere blended with a box, cratered and bumped by noise.
+float roughsphere_sdf(float radius, const Aff& NT, V3 pos) {   // :173-182
+    const float r = 0.8f * radius;
+    const float sd_box = rect_sdf(v3(r, r, r), pos);
+    const float sd_sphere = norm(pos) - radius;   // Sphere::signedDistance src/Geometry.cpp:39-41
+    const float sd = smin(sd_box, sd_sphere, 8.0f);
+    const float craters = std::max(0.0f, -1.0f + 3.0f * fbm_noise(NT, 1.0f * pos));   // :165-167
+    const float bumps = -0.15f + 0.5f * fbm_noise(NT, 4.0f * pos);                    // :169-171
+    return std::min(sd + craters, sd + craters + bumps);
+}
+void roughsphere_material(float radius, const Aff& NT, V3 pos, Material& m);
+
+// WeirdWallObject :273-349: a ground slab, a brick wall with an arch, all eroded by noise.
+float weirdwall_sdf(const Aff& NT, V3 pos) {   // :281-328
+    const float pi = 3.141592654f;
+    const float sdf_ground_clean = rect_sdf(v3(50.0f, 0.2f, 10.0f), pos - v3(0.0f, 3.0f, 0.0f));
+    const float sdf_wall_proxy = rect_sdf(v3(50.0f, 4.0f, 0.4f), pos);
+    const float sdf_proxy = smin(sdf_ground_clean - 0.2f, sdf_wall_proxy, 2.0f);
+    if (sdf_proxy > 0.1f) return sdf_proxy;
+
+    const float sdf_ground = sdf_ground_clean + fbm_noise(NT, pos);
+    const float dist_xy = std::hypot(pos.x, pos.y);
+    const float angle_xy = std::atan2(pos.y, pos.x);
+    const float ring_band = std::abs(dist_xy - 1.5f) - (std::abs(angle_xy + 0.5f * pi) < 0.18f ? 0.5f : 0.3f);
+    const float spoke_spacing = 18.0f;
+    const float scaled_spoke_angle = angle_xy * spoke_spacing * 0.5f / pi;
+    const float spoke_angle = (scaled_spoke_angle - std::round(scaled_spoke_angle)) / spoke_spacing;
+    const float ring_spokes = std::abs(spoke_angle * dist_xy) * (2.0f * pi) - 0.06f;
+    const float arch_ring = std::max(ring_band, -ring_spokes);
+    const float pillar_columns = std::abs(std::abs(pos.x) - 1.5f) - 0.3f;
+    const float slice_spacing = 1.5f;
+    const float pillar_slices = std::abs(pos.y * slice_spacing - std::round(pos.y * slice_spacing)) / slice_spacing - 0.06f;
+    const float arch_pillars = std::max(pillar_columns, -pillar_slices);
+    const float sdf_arch = std::max(pos.y < 0.0f ? arch_ring : arch_pillars, std::abs(pos.z) - 0.3f);
+    const float arch_center = pos.y < 0.0f ? dist_xy : std::abs(pos.x);
+
+    const Voronoi bricks = voronoi(pos + 1.5f * v3(fbm_noise(NT, pos), fbm_noise(NT, pos + v3(10.0f, 10.0f, 10.0f)), 0.0f), 0.3f,
+                                   Lin{{1.0f, 0.5f, 0.0f, 0.0f, 0.5f, 0.0f, 0.0f, 0.0f, 1.0f}});
+    const float bricks_everywhere = std::max(-std::abs(std::sqrt(bricks.sqr) - std::sqrt(bricks.next_sqr)) + 0.05f, std::abs(pos.z) - 0.2f);
+    const float brick_wall = -smin(-std::max(bricks_everywhere, -arch_center + 1.85f), 3.0f + pos.y + std::exp(-0.125f * (pos.x * pos.x)), 2.0f);
+
+    return smin(std::min(brick_wall, sdf_arch), sdf_ground, 3.0f) + 0.23f * fbm_noise(NT, pos * 5.1712f) + 0.06f * fbm_noise(NT, pos * 14.81552f);
+}
 float craterball_sdf(V3 off, const Aff& NT, V3 pos, SdfCounters* cnt) {   // :361-466
     if (cnt) cnt->evals++;
     const float sdf_sphere = norm(pos) - 0.5f;
@@ -562,6 +628,21 @@ V3 sdf_normal(V3 pos, Sdf&& sdf) {   // signedDistanceNormal include/Object.hpp:
     return unit(div(v3(sdf(pos + v3(delta, 0, 0)) - d0, sdf(pos + v3(0, delta, 0)) - d0, sdf(pos + v3(0, 0, delta)) - d0), delta));
 }
 
+// deflectLocalRay :184-199: the material is made of SDF normals taken at two other points.
+void roughsphere_material(float radius, const Aff& NT, V3 pos, Material& m) {
+    auto nrm = [&](V3 q) { return sdf_normal(q, [&](V3 x) { return roughsphere_sdf(radius, NT, x); }); };
+    V3 n1 = nrm((-pos) * 1.724674f + v3(3.474577f, 1.734674f, 2.713652f));
+    V3 n2 = nrm(pos * 2.446744f + v3(1.734674f, 2.713652f, 4.137371f));
+    n1 = v3(0.5f, 0.5f, 0.5f) + 0.5f * n1;
+    n2 = v3(0.5f, 0.5f, 0.5f) + 0.5f * n2;
+    m.albedo = n1;
+    m.diffuse = n2.x;
+    m.specular = 1.0f - n2.x;
+    m.sharpness = n2.y;
+    const float k = 0.125f * n2.z;
+    m.emitted = v3(k * m.albedo.x, k * m.albedo.y, k * m.albedo.z);   // operator*(float, Color) src/Color.cpp:25-31
+}
+
 // FractalObject (src/Object.cpp:160-252): a 3 x 3 x 3 lattice of spheres of radius 0.2.
 float fractal_sdf(V3 p) {   // :198-252
     auto f = [](float v) {
@@ -604,6 +685,12 @@ std::optional<V3> hit_local(uint32_t kind, const float* p, const Aff& noise, con
             const V3 half = v3(p[0], p[1], p[2]);
             return sdf_march(r, Box{v3(0, 0, 0), 2.0f * half}, [&](V3 q) { return roughbox_sdf(half, noise, q); });   // localBoundingBox :261-266
         }
+        case ORC_ROUGHSPHERE: {
+            const float h = 1.2f * p[0];   // localBoundingBox :216-221: `1.2f * radius * Vec(1, 1, 1)`
+            return sdf_march(r, Box{v3(0, 0, 0), v3(h * 1.0f, h * 1.0f, h * 1.0f)}, [&](V3 q) { return roughsphere_sdf(p[0], noise, q); });
+        }
+        case ORC_WEIRDWALL:
+            return sdf_march(r, Box{v3(0, 0, 0), v3(50.0f, 20.0f, 20.0f)}, [&](V3 q) { return weirdwall_sdf(noise, q); });   // :343-348
         case ORC_SPHERE: return hit_sphere(r, p[0]);                                   // src/Object.cpp:116-118
         case ORC_BOX: return hit_rect(r, v3(p[0], p[1], p[2]));                        // :141-143
         case ORC_TRIANGLE: return hit_triangle(r, v3(p[0], p[1], p[2]), v3(p[3], p[4], p[5]), v3(p[6], p[7], p[8]));   // :88-90
@@ -632,6 +719,8 @@ V3 normal_local(uint32_t kind, const float* p, const Aff& noise, V3 pos, SdfCoun
             const V3 half = v3(p[0], p[1], p[2]);
             return sdf_normal(pos, [&](V3 q) { return roughbox_sdf(half, noise, q); });
         }
+        case ORC_ROUGHSPHERE: return sdf_normal(pos, [&](V3 q) { return roughsphere_sdf(p[0], noise, q); });
+        case ORC_WEIRDWALL: return sdf_normal(pos, [&](V3 q) { return weirdwall_sdf(noise, q); });
     }
     return v3(0, 0, 1);
 }
@@ -649,6 +738,11 @@ Box local_bbox(uint32_t kind, const float* p) {   // *::getLocalBoundingBox src/
         }
         case ORC_FRACTAL: return Box{v3(0, 0, 0), v3(2.0f, 2.0f, 2.0f)};   // src/Object.cpp:191-196
         case ORC_ROUGHBOX: return Box{v3(0, 0, 0), 2.0f * v3(p[0], p[1], p[2])};
+        case ORC_ROUGHSPHERE: {
+            const float h = 1.2f * p[0];
+            return Box{v3(0, 0, 0), v3(h * 1.0f, h * 1.0f, h * 1.0f)};
+        }
+        case ORC_WEIRDWALL: return Box{v3(0, 0, 0), v3(50.0f, 20.0f, 20.0f)};
         default: return kCraterBox;
     }
 }
@@ -682,7 +776,9 @@ Bounce deflect_object(const SceneData& s, const Prim& o, const Ray& r, Rng& rng,
     const Ray local{xform_vec(o.inv, r.dir), xform_pos(o.inv, r.pos)};
     const V3 n = normal_local(o.kind, o.p, s.noise, local.pos, cnt);
     Material m = s.mats[o.material];
-    if (o.kind == ORC_ROUGHBOX) m.albedo = roughbox_albedo(local.pos);   // `m.setReflectedAbsorption(...)` :253-257
+    if (o.kind == ORC_ROUGHBOX) m.albedo = foam_albedo(local.pos, 0.2f);   // `m.setReflectedAbsorption(...)` :251-257
+    if (o.kind == ORC_WEIRDWALL) m.albedo = foam_albedo(local.pos, 0.018347f);   // :333-339
+    if (o.kind == ORC_ROUGHSPHERE) roughsphere_material(o.p[0], s.noise, local.pos, m);
     Bounce b = deflect(m, local.dir, n, rng);
     b.dir = xform_vec(o.fwd, b.dir);
     return b;

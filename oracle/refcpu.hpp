@@ -33,7 +33,7 @@ extern "C" {
 
 typedef struct orc_scene orc_scene;
 
-enum { ORC_SPHERE = 0, ORC_BOX = 1, ORC_TRIANGLE = 2, ORC_CRATERBALL = 3, ORC_FRACTAL = 4, ORC_ROUGHBOX = 5 };
+enum { ORC_SPHERE = 0, ORC_BOX = 1, ORC_TRIANGLE = 2, ORC_CRATERBALL = 3, ORC_FRACTAL = 4, ORC_ROUGHBOX = 5, ORC_ROUGHSPHERE = 6, ORC_WEIRDWALL = 7 };
 enum { ORC_RNG_MINSTD = 0, ORC_RNG_COUNTER = 1 };
 
 // ---- linear algebra helpers (src/LinearAlgebra.cpp) --------------------------------------

@@ -14,7 +14,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-SPHERE, BOX, TRIANGLE, CRATERBALL, FRACTAL, ROUGHBOX = 0, 1, 2, 3, 4, 5
+SPHERE, BOX, TRIANGLE, CRATERBALL, FRACTAL, ROUGHBOX, ROUGHSPHERE, WEIRDWALL = 0, 1, 2, 3, 4, 5, 6, 7
 
 IDENTITY12 = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], np.float32)
 
@@ -95,6 +95,14 @@ class SceneBuilder:
     def roughbox(self, half, mat, fwd=None):
         """The demo's RoughBoxObject (PathTracerDemo.cpp:228-270); needs the scene's noise transform."""
         return self._add(ROUGHBOX, list(half), mat, fwd)
+
+    def roughsphere(self, radius, mat, fwd=None):
+        """The demo's RoughSphereObject (PathTracerDemo.cpp:156-226); needs the scene's noise transform."""
+        return self._add(ROUGHSPHERE, [radius], mat, fwd)
+
+    def weirdwall(self, mat, fwd=None):
+        """The demo's WeirdWallObject (PathTracerDemo.cpp:273-349); needs the scene's noise transform."""
+        return self._add(WEIRDWALL, [], mat, fwd)
 
     def fractal(self, mat, fwd=None):
         """FractalObject (include/Object.hpp:179-192): no parameters beyond its material."""

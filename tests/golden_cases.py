@@ -101,6 +101,17 @@ def make_inputs():
     o[:16] = r.uniform(-0.9, 0.9, (16, 3)) * [1.0, 0.8, 1.2]      # origins inside the bounding box
     inp["rb_ray_pos"], inp["rb_ray_dir"] = o.astype(np.float32), dd.astype(np.float32)
 
+    # --- RoughSphereObject / WeirdWallObject (local frame)
+    r = _rs(9)
+    o = _unit(r.normal(size=(200, 3))) * r.uniform(1.6, 3.0, (200, 1))
+    dd = _unit(r.uniform(-0.7, 0.7, (200, 3)) - o) * r.choice([0.5, 1.0, 1.6], (200, 1))
+    o[:12] = r.uniform(-1.1, 1.1, (12, 3))
+    inp["rs_ray_pos"], inp["rs_ray_dir"] = o.astype(np.float32), dd.astype(np.float32)
+    o = np.stack([r.uniform(-4, 4, 200), r.uniform(-3.5, 3.2, 200), r.uniform(-6, -3, 200)], axis=1)
+    dd = _unit(np.stack([r.uniform(-0.3, 0.3, 200), r.uniform(-0.3, 0.3, 200), np.ones(200)], axis=1))
+    o[:10] = np.stack([r.uniform(-3, 3, 10), r.uniform(-3, 2, 10), r.uniform(-0.5, 0.5, 10)], axis=1)   # origins near or inside the wall
+    inp["ww_ray_pos"], inp["ww_ray_dir"] = o.astype(np.float32), dd.astype(np.float32)
+
     # --- camera
     g = np.linspace(0, 1, 9, dtype=np.float32)
     sx, sy = np.meshgrid(g, g)
@@ -204,6 +215,28 @@ def roughbox_scene(alg, noise):
 
 def roughbox_camera(alg, aspect=1.0):
     return S.camera(S.translation(0.0, 0.0, -8.0), aspect=aspect, fov=14.0, focal=10.0, blur=0.0)
+
+
+def roughsphere_scene(alg, noise):
+    """The demo's RoughSphereObject (its material is procedural: every hit emits a little), a floor and a light."""
+    b = S.SceneBuilder(alg, noise)
+    t = alg.affine_mul(S.translation(-0.1, 0.2, 0.1), alg.affine_mul(S.linear_to_affine(alg.rotation("y", 0.4)), S.scale(1.2)))
+    b.roughsphere(1.0, S.material(diffuse=0.9, specular=0.1, sharpness=0.5), t)
+    b.box((6.0, 0.1, 6.0), S.material(diffuse=1.0, specular=0.0, albedo=(0.7, 0.7, 0.7)), S.translation(0.0, 2.4, 0.0))
+    b.box((2.0, 0.05, 2.0), S.material(diffuse=1.0, specular=0.0, emitted=(12.0, 11.0, 10.0)), S.translation(0.0, -5.0, 0.0))
+    return b.build()
+
+
+def weirdwall_scene(alg, noise):
+    """The demo's WeirdWallObject (ground, brick wall, arch) under a light."""
+    b = S.SceneBuilder(alg, noise)
+    b.weirdwall(S.material(diffuse=0.9, specular=0.1, sharpness=0.5))
+    b.box((4.0, 0.05, 2.0), S.material(diffuse=1.0, specular=0.0, emitted=(12.0, 11.0, 10.0)), S.translation(0.0, -7.0, -4.0))
+    return b.build()
+
+
+def sdf_camera(alg, z=-8.0, fov=14.0, y=0.0):
+    return S.camera(S.translation(0.0, y, z), aspect=1.0, fov=fov, focal=10.0, blur=0.0)
 
 
 def fractal_camera(alg, aspect=1.0):
@@ -433,6 +466,19 @@ def evaluate(be, inp, heavy=True):
         out["rb_primary_prim"], out["rb_primary_t"] = sc.primary_hits(rcam, 40, 40)
         out["rb_trace"] = be.trace(sc, o[:80] * 0.9, d[:80], 5, 8)
         out["rb_render"] = be.render(sc, rcam, 24, 24, 5, 2, 27)
+
+        # RoughSphereObject and WeirdWallObject
+        for tag, kind, prm, mk, cam_ in (("rs", 6, np.array([1.0] + [0.0] * 8, np.float32), roughsphere_scene, sdf_camera(alg, -8.0, 14.0)),
+                                         ("ww", 7, np.zeros(9, np.float32), weirdwall_scene, sdf_camera(alg, -14.0, 20.0, -0.5))):
+            hit, pos = be.hit_local(kind, prm, inp[tag + "_ray_pos"], inp[tag + "_ray_dir"])
+            out[tag + "_hit"], out[tag + "_hitpos"] = hit, pos
+            out[tag + "_normal"] = be.normal_local(kind, prm, pos[hit][:32])
+            fs = mk(alg, be.noise)
+            out[tag + "_bbox"] = api.world_bbox(kind, fs.fwd[0], prm)
+            sc = be.scene(fs)
+            out[tag + "_primary_prim"], out[tag + "_primary_t"] = sc.primary_hits(cam_, 32, 32)
+            out[tag + "_trace"] = be.trace(sc, o[:60] * 0.9, d[:60], 4, 8)
+            out[tag + "_render"] = be.render(sc, cam_, 16, 16, 4, 2, 27)
 
     if heavy:
         dm = S.demo_scene(alg, be.noise)
