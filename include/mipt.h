@@ -34,8 +34,12 @@ typedef struct mipt_ctx mipt_ctx;
 typedef struct mipt_scene mipt_scene;
 
 /* Primitive kinds: the concrete Object subclasses (include/Object.hpp:60-102, 179-192) and the demo's
- * CraterBallObject (PathTracerDemo.cpp:352-483) and RoughBoxObject (PathTracerDemo.cpp:228-270). */
-enum { MIPT_SPHERE = 0, MIPT_BOX = 1, MIPT_TRIANGLE = 2, MIPT_CRATERBALL = 3, MIPT_FRACTAL = 4, MIPT_ROUGHBOX = 5 };
+ * SDF objects: CraterBallObject (PathTracerDemo.cpp:352-483), RoughBoxObject (:228-270), RoughSphereObject
+ * (:156-226) and WeirdWallObject (:273-349). */
+enum {
+    MIPT_SPHERE = 0, MIPT_BOX = 1, MIPT_TRIANGLE = 2, MIPT_CRATERBALL = 3, MIPT_FRACTAL = 4, MIPT_ROUGHBOX = 5,
+    MIPT_ROUGHSPHERE = 6, MIPT_WEIRDWALL = 7
+};
 
 /* What Scene::updateGeometry (src/Scene.cpp:80-87) flattens its objects into.  Arrays are copied
  * by mipt_scene_upload; the caller keeps ownership.
@@ -44,12 +48,13 @@ enum { MIPT_SPHERE = 0, MIPT_BOX = 1, MIPT_TRIANGLE = 2, MIPT_CRATERBALL = 3, MI
  *               Object::setTransformation caches (mipt_affine_inverse computes exactly that).
  *   params      9 floats per primitive: sphere {radius}; box {half x,y,z}; triangle {a, b, c};
  *               crater ball {offset x,y,z}; fractal {} (FractalObject has no parameters);
- *               rough box {Rectangle::halfSize x,y,z} (each below 7e4)
+ *               rough box {Rectangle::halfSize x,y,z} (each below 7e4); rough sphere {Sphere::radius};
+ *               weird wall {}
  *   materials   14 floats per row in BasicMaterial's member order (include/BasicMaterial.hpp:32-39):
  *               diffuse, specular, sharpness, reflected absorption rgb, emitted luminance rgb,
  *               transmittance, index of refraction, internal absorption rgb
  *   noise_transform  the demo's noiseTransform() (PathTracerDemo.cpp:37-54), 12 floats; may be NULL
- *               when the scene holds no crater ball and no rough box */
+ *               when the scene holds none of the demo's SDF objects */
 typedef struct {
     uint32_t n_prims;
     const uint32_t* kind;

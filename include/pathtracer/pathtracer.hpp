@@ -380,10 +380,10 @@ template <typename Derived>
 struct DeviceSdf {
     static bool describe(const Derived&, DevicePrimitive&) noexcept { return false; }
 };
-// Recognises the reference demo's own CraterBallObject (PathTracerDemo.cpp:352-483) and RoughBoxObject
-// (PathTracerDemo.cpp:228-270), which cannot opt in because the demo is compiled unchanged: the class is
-// identified by its name and size, and its one data member (the noise offset / the Rectangle, three floats
-// that follow the SDFObjectCRTP base) is read in place.
+// Recognises the reference demo's own SDF classes (CraterBallObject, RoughBoxObject, RoughSphereObject,
+// WeirdWallObject; PathTracerDemo.cpp:156-483), which cannot opt in because the demo is compiled
+// unchanged: a class is identified by its name and size, and its parameters (the noise offset, the
+// Rectangle, the Sphere: floats that follow the SDFObjectCRTP base) are read in place.
 bool describeKnownDemoSdf(const char* mangled_name, std::size_t derived_size, std::size_t base_size, const void* object,
                           DevicePrimitive& out) noexcept;
 }   // namespace mipt_host

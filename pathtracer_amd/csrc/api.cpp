@@ -512,10 +512,10 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     bool any_tri = false, any_sdf = false /* crater balls */, any_plain = false /* SDF kinds evaluated one point per lane */;
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t k = d->kind[i];
-        if (k > MIPT_ROUGHBOX || d->material[i] >= d->n_materials) return MIPT_ERR_ARGUMENT;
+        if (k > MIPT_WEIRDWALL || d->material[i] >= d->n_materials) return MIPT_ERR_ARGUMENT;
         any_tri |= (k == MIPT_TRIANGLE);
         any_sdf |= (k == MIPT_CRATERBALL);
-        any_plain |= (k == MIPT_ROUGHBOX);
+        any_plain |= (k >= MIPT_ROUGHBOX);
     }
     if ((any_sdf || any_plain) && !d->noise_transform) return MIPT_ERR_ARGUMENT;
     if (any_tri) tri_c.assign(static_cast<size_t>(3) * n, 0.0f);

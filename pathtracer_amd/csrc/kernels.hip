@@ -814,8 +814,9 @@ __device__ __forceinline__ int march_step(March& m, float d2, f3 box) {
     return ++m.iter >= 256u ? 2 : 0;
 }
 
-// PLAIN: the scene holds SDF kinds that are evaluated one point per lane (RoughBoxObject); scenes
-// without them run the instantiation that does not carry that code.
+// PLAIN: the scene holds SDF kinds that are evaluated one point per lane (RoughBoxObject,
+// RoughSphereObject, WeirdWallObject); scenes without them run the instantiation that does not carry
+// that code.
 template <bool PLAIN>
 __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
     if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
@@ -829,7 +830,8 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
     f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv_d = mk3(0, 0, 0), off = mk3(0, 0, 0), best_pos = mk3(0, 0, 0);
     float inv_len2 = 0.0f, limit = 0.0f;
     unsigned long long best = kMissKey;
-    bool improved = false, plain = false;
+    bool improved = false;
+    uint32_t plain = 0;   // kind of the lane-evaluated object being marched, 0 for a crater ball
     const f3 ball_box = mk3(1.0f, 1.0f, 1.0f);   // CraterBallObject::localBoundingBox PathTracerDemo.cpp:474-479
     uint32_t c_far = 0, c_near = 0, c_noise = 0;
     __shared__ __attribute__((aligned(16))) float s_coop[4 * kNearLdsFloats];
@@ -912,8 +914,8 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
                 crater_count = __float_as_uint(pr->p[4]);
                 f3 box = ball_box;
                 if (PLAIN) {
-                    plain = pr->kind == 5u;
-                    if (plain) box = mk3(2.0f * off.x, 2.0f * off.y, 2.0f * off.z);   // RoughBoxObject::localBoundingBox :261-266 (p[0..2] = halfSize)
+                    plain = pr->kind >= 5u ? pr->kind : 0u;
+                    if (plain) box = plain_box(plain, off);   // `off` holds the object's first three parameters
                 }
                 bool ok = true;
                 f3 p0 = lo;
@@ -935,9 +937,9 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
         int result = 0;
         float s = 0.0f;
         if (PLAIN && state == MARCH && plain) {
-            // one step of a lane-evaluated object (`off` holds the box's halfSize)
+            // one step of a lane-evaluated object
             ++c_near;
-            result = march_step(m, roughbox_sdf(off, sc.noise_raw, m.p), mk3(2.0f * off.x, 2.0f * off.y, 2.0f * off.z));
+            result = march_step(m, plain_sdf(plain, off, sc.noise_raw, m.p), plain_box(plain, off));
         } else if (state == MARCH) {
             for (;;) {
                 s = norm(m.p) - 0.5f;
@@ -1089,7 +1091,8 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
         PrimRegs pr;
         f3 wp = mk3(0, 0, 0), ld = mk3(0, 0, 0), p = mk3(0, 0, 0), off = mk3(0, 0, 0), local_hit = mk3(0, 0, 0);
         float s = 0.0f;
-        bool fractal = false, plain = false;
+        bool fractal = false;
+        uint32_t plain = 0;   // kind of a lane-evaluated object, else 0
         if (valid) {
             slot = pb.sdf_shade_queue[i];
             const uint32_t prim = static_cast<uint32_t>(pb.hit_key[slot] & 0xffffffffu);
@@ -1099,7 +1102,7 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
             ld = lin_mul(pr.inv, d);
             const f3 lp = aff_pos(pr.inv, wp);
             fractal = pr.kind == 4u;
-            if (PLAIN) plain = pr.kind == 5u;
+            if (PLAIN) plain = pr.kind >= 5u ? pr.kind : 0u;
             local_hit = lp;
             if (!fractal) {
                 off = mk3(pr.p[0], pr.p[1], pr.p[2]);
@@ -1113,7 +1116,23 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
         // the far field returns the sphere distance itself (`sdf_sphere > 0.1` compares against a double literal)
         const bool wants = valid && !fractal && !(PLAIN && plain) && !(static_cast<double>(s) > 0.1);
         float v = s;
-        if (PLAIN && plain) v = roughbox_sdf(off, sc.noise_raw, p);   // each lane of the quad evaluates its own point
+        // Lane-evaluated kinds: each lane of the quad evaluates its own point of the forward difference
+        // (a quad shares one hit, so the branch is uniform over the quad and the broadcasts are safe).
+        f3 plain_n = mk3(0, 0, 1), plain_n1 = mk3(0, 0, 0), plain_n2 = mk3(0, 0, 0);
+        if (PLAIN && plain) {
+            const auto quad_normal = [&](f3 base) {
+                const f3 q = mk3(base.x + (e == 1u ? delta : 0.0f), base.y + (e == 2u ? delta : 0.0f), base.z + (e == 3u ? delta : 0.0f));
+                const float w = plain_sdf(plain, off, sc.noise_raw, q);
+                const float w0 = dpp_f<0x00>(0.0f, w), w1 = dpp_f<0x55>(0.0f, w), w2 = dpp_f<0xAA>(0.0f, w), w3 = dpp_f<0xFF>(0.0f, w);
+                return unit(mk3(w1 - w0, w2 - w0, w3 - w0) * (1.0f / delta));
+            };
+            plain_n = quad_normal(local_hit);
+            if (plain == 6u) {   // RoughSphereObject's material is made of normals at two other points (PathTracerDemo.cpp:187-188)
+                plain_n1 = quad_normal((-local_hit) * 1.724674f + mk3(3.474577f, 1.734674f, 2.713652f));
+                plain_n2 = quad_normal(local_hit * 2.446744f + mk3(1.734674f, 2.713652f, 4.137371f));
+                c_evals += 2;
+            }
+        }
         wave_near(sc.craters, cl, lds, lane, bp.lane_threshold, wants, p, off, s, crater_base, crater_count, v, c_near, c_noise);
         const float v0 = dpp_f<0x00>(0.0f, v), v1 = dpp_f<0x55>(0.0f, v), v2 = dpp_f<0xAA>(0.0f, v), v3 = dpp_f<0xFF>(0.0f, v);   // quad broadcasts
         bool alive = false;
@@ -1121,6 +1140,8 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
             f3 nrm;
             if (fractal) {
                 nrm = fractal_normal(local_hit);   // six cheap evaluations on the quad's first lane
+            } else if (PLAIN && plain) {
+                nrm = plain_n;
             } else {
                 const f3 g = mk3(v1 - v0, v2 - v0, v3 - v0) * (1.0f / delta);
                 nrm = unit(g);
@@ -1130,9 +1151,22 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
             pixel_of(bp, slot - s_local * bp.n_pix, px, py);
             Rng rng(bp.seed, py * bp.width + px, bp.first_sample + s_local, 1u + bounce);
             Bounce b;
-            if (PLAIN && plain) {   // `m.setReflectedAbsorption(...)` PathTracerDemo.cpp:253-257
+            if (PLAIN && plain) {   // the procedural materials of PathTracerDemo.cpp:184-199, 248-259, 330-341
                 MaterialRec mat = sc.materials[pr.material];
-                const f3 a = roughbox_albedo(local_hit);
+                f3 a;
+                if (plain == 6u) {
+                    a = mk3(0.5f, 0.5f, 0.5f) + 0.5f * plain_n1;
+                    const f3 n2 = mk3(0.5f, 0.5f, 0.5f) + 0.5f * plain_n2;
+                    mat.diffuse = n2.x;
+                    mat.specular = 1.0f - n2.x;
+                    mat.sharpness = n2.y;
+                    const float k = 0.125f * n2.z;
+                    mat.emitted[0] = k * a.x;
+                    mat.emitted[1] = k * a.y;
+                    mat.emitted[2] = k * a.z;
+                } else {
+                    a = foam_albedo(local_hit, plain == 5u ? 0.2f : 0.018347f);
+                }
                 mat.albedo[0] = a.x;
                 mat.albedo[1] = a.y;
                 mat.albedo[2] = a.z;

@@ -421,18 +421,33 @@ float FractalObject::signedDistance(const Pos& p) const noexcept {
 }
 
 // ================================================================================================
-// the demo's CraterBallObject and RoughBoxObject, recognised without their cooperation
+// the demo's SDF classes, recognised without their cooperation
 // ================================================================================================
 bool mipt_host::describeKnownDemoSdf(const char* name, std::size_t derived_size, std::size_t base_size, const void* object, DevicePrimitive& out) noexcept {
-    // Itanium mangling of a global class: <length><name>.  Either class has exactly one data member laid out
-    // directly behind the SDFObjectCRTP base: CraterBallObject a Vec (PathTracerDemo.cpp:481-482),
-    // RoughBoxObject a Rectangle, which is its halfSize Vec (PathTracerDemo.cpp:268-269, include/Geometry.hpp).
+    // Itanium mangling of a global class: <length><name>.  The data members lie directly behind the
+    // SDFObjectCRTP base: CraterBallObject a Vec (PathTracerDemo.cpp:481-482); RoughBoxObject a Rectangle, which is
+    // its halfSize Vec (:268-269); RoughSphereObject a Sphere, which is its radius, then a BasicMaterial (:223-225);
+    // WeirdWallObject nothing.
     static_assert(sizeof(Rectangle) == sizeof(Vec), "Rectangle is its halfSize");
+    static_assert(sizeof(Sphere) == sizeof(float), "Sphere is its radius");
+    const auto pad8 = [](std::size_t n) { return (n + 7) / 8 * 8; };
+    const char* members = static_cast<const char*>(object) + base_size;
+    if (std::strcmp(name, "15WeirdWallObject") == 0) {
+        if (derived_size != base_size) return false;
+        out.kind = MIPT_WEIRDWALL;
+        return true;
+    }
+    if (std::strcmp(name, "17RoughSphereObject") == 0) {
+        if (derived_size != pad8(base_size + sizeof(Sphere) + sizeof(BasicMaterial))) return false;
+        std::memcpy(&out.params[0], members, sizeof(float));
+        out.kind = MIPT_ROUGHSPHERE;
+        return true;
+    }
     const bool ball = std::strcmp(name, "16CraterBallObject") == 0, box = std::strcmp(name, "14RoughBoxObject") == 0;
     if (!ball && !box) return false;
-    if (derived_size < base_size + sizeof(Vec) || derived_size > base_size + sizeof(Vec) + 8) return false;
+    if (derived_size != pad8(base_size + sizeof(Vec))) return false;
     float off[3];
-    std::memcpy(off, static_cast<const char*>(object) + base_size, sizeof(off));
+    std::memcpy(off, members, sizeof(off));
     out.kind = ball ? MIPT_CRATERBALL : MIPT_ROUGHBOX;
     out.params[0] = off[0];
     out.params[1] = off[1];
@@ -650,12 +665,12 @@ mipt_scene* sync_scene(const Scene& scene) {
         if (d.kind < 0 || !d.material) {
             std::fprintf(stderr,
                          "pathtracer: object %zu (type %s) has no device counterpart: supported are SphereObject, BoxObject, TriangleObject, FractalObject, the demo's "
-                         "CraterBallObject and RoughBoxObject and SDF classes that specialise mipt_host::DeviceSdf.\n",
+                         "CraterBallObject, RoughBoxObject, RoughSphereObject and WeirdWallObject, and SDF classes that specialise mipt_host::DeviceSdf.\n",
                          i, d.type_name);
             std::abort();
         }
         kind[i] = static_cast<uint32_t>(d.kind);
-        any_sdf |= d.kind == MIPT_CRATERBALL || d.kind == MIPT_ROUGHBOX;
+        any_sdf |= d.kind == MIPT_CRATERBALL || d.kind >= MIPT_ROUGHBOX;
         if (d.noise && !own_noise) own_noise = d.noise;
         material[i] = static_cast<uint32_t>(i);
         affine_to(objs[i]->transformation(), &fwd[12 * i]);
@@ -668,7 +683,7 @@ mipt_scene* sync_scene(const Scene& scene) {
         std::memcpy(noise, own_noise, sizeof(noise));   // one noise transform per scene: the first CraterBall's
     } else if (any_sdf) {
         if (!&noiseTransform) {
-            std::fprintf(stderr, "pathtracer: the scene holds a crater ball or a rough box but the program defines no noiseTransform()\n");
+            std::fprintf(stderr, "pathtracer: the scene holds one of the demo's SDF objects but the program defines no noiseTransform()\n");
             std::abort();
         }
         affine_to(noiseTransform(), noise);

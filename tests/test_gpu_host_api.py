@@ -69,8 +69,8 @@ def test_renderer_class_matches_c_abi(ctx):
 
 
 def test_unchanged_demo_classes_render_on_the_gpu(ctx):
-    """The reference demo's own CraterBallObject (compiled unchanged into the harness) is recognised by
-    Scene flattening, its noiseTransform() is picked up, and the frame equals the C ABI's."""
+    """The reference demo's own SDF classes (compiled unchanged into the harness) are recognised by
+    Scene flattening, the demo's noiseTransform() is picked up, and the frames equal the C ABI's."""
     if not os.path.exists(HARNESS_DEMO):
         pytest.skip("oracle/_ref/libhost_harness_demo.so not built (needs the reference checkout at build time)")
     host = orc.Reference(HARNESS_DEMO)
@@ -82,3 +82,11 @@ def test_unchanged_demo_classes_render_on_the_gpu(ctx):
     want, st = ctx.render(ctx.upload(flat), cam, 40, 40, 8, 2, seed=DEFAULT_SEED)
     assert st["sdf_shades"] > 100
     assert np.array_equal(got, want)
+    # RoughBoxObject, RoughSphereObject and WeirdWallObject of the same unchanged block
+    for flat, cam in ((G.roughbox_scene(alg, noise), G.roughbox_camera(alg)),
+                      (G.roughsphere_scene(alg, noise), G.sdf_camera(alg, -8.0, 14.0)),
+                      (G.weirdwall_scene(alg, noise), G.sdf_camera(alg, -14.0, 20.0, -0.5))):
+        got = host.scene(flat).render(cam, 32, 32, 4, 2, seed=1, threads=1)
+        want, st = ctx.render(ctx.upload(flat), cam, 32, 32, 4, 2, seed=DEFAULT_SEED)
+        assert st["sdf_shades"] > 100
+        assert np.array_equal(got, want)
