@@ -52,6 +52,9 @@ def parse():
     p.add_argument("--scene", default="demo", choices=["demo", "random100k", "random1m", "mixed20k"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-spp", type=int, default=64, help="samples per pixel of the CPU baseline's bounded sample")
+    p.add_argument("--rehearse", action="store_true",
+                   help="every rank uses cuda:0 and the all-reduce runs over gloo: checks the multi-process path on a one-GPU box, "
+                        "measures nothing (the JSON line says so)")
     return p.parse_args()
 
 
@@ -75,11 +78,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
+    if a.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist   # RCCL behind the "nccl" backend
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
 
@@ -170,7 +178,7 @@ def main():
         "scaling": a.scaling,
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not a.rehearse else "synthetic; REHEARSAL: all ranks on one GPU over gloo, not a measurement",
         "config": {"workload": f"{scene_label}, {W}x{H}, {frame_spp} spp per frame ({my_spp} per GPU), {a.bounces} bounces, filmic tone map on GPU",
                    "primitives": flat.n_prims, "parallelism": f"spp-shard x{world} + RCCL all-reduce" if world > 1 else "single GPU",
                    "scene_upload_s": round(upload_s, 4)},
