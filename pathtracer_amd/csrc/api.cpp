@@ -62,6 +62,7 @@ struct mipt_scene {
     void* d_sdf = nullptr;
     void* d_oct = nullptr;
     void* d_craters = nullptr;
+    void* d_crater_masks = nullptr;
     uint32_t n_nodes = 0, n_analytic = 0, n_sdf = 0;
     int depth = 0;
     // padded world boxes that together hold everything a ray can hit: the analytic primitives' common
@@ -597,6 +598,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     // cells of a cube that covers the shell (|cell - offset| <= 2 + 0.3 + sqrt(0.1) < 3), with the very
     // arithmetic the kernels use; the cells that pass are kept in lattice order.
     std::vector<float> craters;
+    std::vector<unsigned long long> crater_masks;
     if (any_sdf) {
         constexpr int kCube = 9;
         constexpr size_t kCells = size_t(kCube) * kCube * kCube;
@@ -630,8 +632,25 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
                 (void)hipFree(d_cells);
                 return MIPT_ERR_TOO_LARGE;
             }
+            // cell -> crater mask: crater c is visited from a query in cell f iff cell_c - f is -1, 0, 1 or 2 on every
+            // axis (for_each_nearby_scattered_point with radius 2, PathTracerDemo.cpp:87-93)
+            const uint32_t ordinal = static_cast<uint32_t>(crater_masks.size() / kCells);
+            crater_masks.resize(crater_masks.size() + kCells, 0ull);
+            unsigned long long* masks = crater_masks.data() + static_cast<size_t>(ordinal) * kCells;
+            for (uint32_t cidx = 0; cidx < count; ++cidx) {
+                const float* rec = &craters[12 * static_cast<size_t>(first + cidx)];
+                const int cell[3] = {static_cast<int>(rec[0]), static_cast<int>(rec[1]), static_cast<int>(rec[2])};
+                for (int dx = -1; dx <= 2; ++dx)
+                    for (int dy = -1; dy <= 2; ++dy)
+                        for (int dz = -1; dz <= 2; ++dz) {
+                            const int f[3] = {cell[0] - dx - base[0], cell[1] - dy - base[1], cell[2] - dz - base[2]};
+                            if (f[0] < 0 || f[0] >= kCube || f[1] < 0 || f[1] >= kCube || f[2] < 0 || f[2] >= kCube) continue;
+                            masks[(static_cast<size_t>(f[0]) * kCube + f[1]) * kCube + f[2]] |= 1ull << cidx;
+                        }
+            }
+            const uint32_t packed = count | (ordinal << 8);
             std::memcpy(&r.p[3], &first, 4);
-            std::memcpy(&r.p[4], &count, 4);
+            std::memcpy(&r.p[4], &packed, 4);
         }
         (void)hipFree(d_cells);
     }
@@ -678,6 +697,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
         }
         if (e == hipSuccess) e = upload(&s->d_oct, oct, sizeof(oct));
         if (e == hipSuccess) e = upload(&s->d_craters, craters.data(), craters.size() * sizeof(float));
+        if (e == hipSuccess) e = upload(&s->d_crater_masks, crater_masks.data(), crater_masks.size() * sizeof(unsigned long long));
     }
     if (e != hipSuccess) {
         c->last_hip = static_cast<int>(e);
@@ -693,6 +713,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     s->dev.noise_raw = s->d_oct ? static_cast<const float*>(s->d_oct) + 8 * 13 : nullptr;
     s->dev.plain_sdf = any_plain ? 1u : 0u;
     s->dev.craters = static_cast<const float*>(s->d_craters);
+    s->dev.crater_masks = static_cast<const unsigned long long*>(s->d_crater_masks);
     s->dev.n_sdf = static_cast<uint32_t>(sdf.size());
     s->dev.n_prims = n;
     {
@@ -728,7 +749,7 @@ void mipt_scene_free(mipt_scene* s) {
     if (!s) return;
     // hipFree waits for work that still uses the memory; the context may already be gone
     (void)hipSetDevice(s->device);
-    for (void* p : {s->d_prims, s->d_tri, s->d_mats, s->d_nodes, s->d_sdf, s->d_oct, s->d_craters})
+    for (void* p : {s->d_prims, s->d_tri, s->d_mats, s->d_nodes, s->d_sdf, s->d_oct, s->d_craters, s->d_crater_masks})
         if (p) (void)hipFree(p);
     delete s;
 }

@@ -431,9 +431,12 @@ __device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, float4
 }
 
 // =============================================================================================
-// lane_near: one point per lane.  A wave-uniform loop walks the ball's crater table (lane c holds crater
-// c; the loop reads it into scalar registers with readlane, so no step waits for memory), the small and
-// tiny craters go cell by cell, and only noise() stays cooperative: every
+// lane_near: one point per lane.  Which craters of the ball's table lie within reach of a point depends
+// only on the lattice cell of its query, so a table made at upload maps that cell to a 64-bit mask of
+// crater indices; every lane walks ITS OWN mask, fetching crater c's record from lane c (which holds it)
+// through the LDS crossbar (ds_bpermute: no memory, no bank conflicts).  The loop runs as long as the
+// longest list of the wave (about 17 steps where a scan of the whole table took 26 with 40 % of the
+// lanes busy).  The small and tiny craters go cell by cell, and only noise() stays cooperative: every
 // lane stages the arguments of its calls in a ring in LDS, and rounds of 16 calls drain the ring whenever
 // half of it is full, writing each value to the LDS slot its owner named.
 // =============================================================================================
@@ -470,13 +473,25 @@ __device__ __forceinline__ void noise_ring_rounds(const CoopLane& cl, float* lds
 __device__ __forceinline__ float4 bcast_lane4(float4 v, int lane) {
     return make_float4(bcast_lane(v.x, lane), bcast_lane(v.y, lane), bcast_lane(v.z, lane), bcast_lane(v.w, lane));
 }
+// v of lane (addr / 4), per lane
+__device__ __forceinline__ float fetch_lane(float v, int addr) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); }
+
+constexpr int kCellCube = 9;   // lattice cells per axis about floor(offset) - 4 that a query (offset + 2 u, |u| = 1) can fall into
+// Index into a ball's cell -> crater-mask table (kCellCube^3 entries).
+__device__ __forceinline__ uint32_t crater_cell_index(f3 query, f3 off) {
+    const int ix = static_cast<int>(floorf(query.x) - (floorf(off.x) - 4.0f));
+    const int iy = static_cast<int>(floorf(query.y) - (floorf(off.y) - 4.0f));
+    const int iz = static_cast<int>(floorf(query.z) - (floorf(off.z) - 4.0f));
+    const int hi = kCellCube - 1;
+    return static_cast<uint32_t>((min(max(ix, 0), hi) * kCellCube + min(max(iy, 0), hi)) * kCellCube + min(max(iz, 0), hi));
+}
 
 // Evaluates the near field at `pos` for every lane with `active` set; all 64 lanes must call and the
-// crater table (lane c holds crater c in t0..t2, `count` <= 64) is the same for all of them.  Returns
-// false for a lane whose point has more fallout deposits than a lane can hold; its `out` is then not
-// written.
-__device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, uint32_t count, const CoopLane& cl, float* lds, bool active, f3 pos,
-                                          f3 off, float s, uint32_t lane, float& out, uint32_t& noise_calls) {
+// crater table (lane c holds crater c in t0..t2) with its cell masks is the same for all of them.
+// Returns false for a lane whose point has more fallout deposits than a lane can hold; its `out` is
+// then not written.
+__device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, const unsigned long long* cell_masks, const CoopLane& cl, float* lds, bool active,
+                                          f3 pos, f3 off, float s, uint32_t lane, float& out, uint32_t& noise_calls) {
     float* rx = lds;
     float* ry = lds + kRing;
     float* rz = lds + 2 * kRing;
@@ -485,7 +500,7 @@ __device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, uint3
     constexpr uint32_t kFin = kCol + 4 * 64 * kLaneDeposits;        // the two final noise values of lane l at kFin + 2 l
     f3 u, query;
     near_frame(pos, off, u, query);
-    const f3 fl = mk3(floorf(query.x) + 0.5f, floorf(query.y) + 0.5f, floorf(query.z) + 0.5f);
+    unsigned long long todo = active ? cell_masks[crater_cell_index(query, off)] : 0ull;   // craters within reach of this lane's query
     // the two final noise() calls of every active lane open the ring
     const unsigned long long am = __ballot(active);
     uint32_t staged = 2u * static_cast<uint32_t>(__popcll(am)), done = 0;
@@ -506,14 +521,13 @@ __device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, uint3
     int big_fix = 0;
     uint32_t min_age = 0xffffu, n_dep = 0;
     bool overflow = false;
-    for (uint32_t c = 0; c < count; ++c) {
-        const int ci = static_cast<int>(c);
-        float4 r0 = make_float4(bcast_lane(t0.x, ci), bcast_lane(t0.y, ci), bcast_lane(t0.z, ci), 0.0f);
-        const bool in = active && crater_in_reach(r0, fl);
-        if (!__ballot(in)) continue;
-        r0.w = bcast_lane(t0.w, ci);
-        const float4 r1 = bcast_lane4(t1, ci);
-        const float4 r2 = make_float4(bcast_lane(t2.x, ci), bcast_lane(t2.y, ci), 0.0f, 0.0f);
+    while (__ballot(todo != 0ull)) {
+        const bool in = todo != 0ull;
+        const int from = in ? 4 * __builtin_ctzll(todo) : 0;   // byte address of the lane that holds this lane's next crater
+        todo &= todo - 1ull;
+        const float4 r0 = make_float4(fetch_lane(t0.x, from), fetch_lane(t0.y, from), fetch_lane(t0.z, from), fetch_lane(t0.w, from));
+        const float4 r1 = make_float4(fetch_lane(t1.x, from), fetch_lane(t1.y, from), fetch_lane(t1.z, from), fetch_lane(t1.w, from));
+        const float4 r2 = make_float4(fetch_lane(t2.x, from), fetch_lane(t2.y, from), 0.0f, 0.0f);
         bool dep = false;
         BigCrater b = {};
         if (in) {
@@ -599,13 +613,16 @@ __device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, uint3
 // lanes wait, otherwise (and for the rare point lane_near leaves over) the whole wave works on groups
 // of four points, then on single points.
 // =============================================================================================
-__device__ __forceinline__ void wave_near(const float* crater_table, const CoopLane& cl, float* lds, uint32_t lane, uint32_t lane_threshold, bool wants,
+__device__ __forceinline__ void wave_near(const float* crater_table, const unsigned long long* crater_masks, const CoopLane& cl, float* lds, uint32_t lane, uint32_t lane_threshold, bool wants,
                                           f3 p, f3 off, float s, uint32_t crater_base, uint32_t crater_count, float& value, uint32_t& n_evals,
                                           uint32_t& n_noise) {
     unsigned long long todo = __ballot(wants);
     while (todo) {
         const int first = __ffsll(static_cast<long long>(todo)) - 1;
-        const uint32_t base = bcast_lane_u(crater_base, first), count = bcast_lane_u(crater_count, first);
+        // `crater_count`: the table's length in the low 8 bits, the ball's ordinal among the scene's crater balls above
+        const uint32_t base = bcast_lane_u(crater_base, first), packed = bcast_lane_u(crater_count, first);
+        const uint32_t count = packed & 0xffu;
+        const unsigned long long* cell_masks = crater_masks + static_cast<size_t>(packed >> 8) * (kCellCube * kCellCube * kCellCube);
         const bool mine = wants && crater_base == base;
         unsigned long long need = __ballot(mine);
         todo &= ~need;
@@ -620,7 +637,7 @@ __device__ __forceinline__ void wave_near(const float* crater_table, const CoopL
         if (static_cast<uint32_t>(__popcll(need)) >= lane_threshold) {
             float v = 0.0f;
             uint32_t calls = 0;
-            const bool ok = lane_near(r0, r1, r2, count, cl, lds, mine, p, off, s, lane, v, calls);
+            const bool ok = lane_near(r0, r1, r2, cell_masks, cl, lds, mine, p, off, s, lane, v, calls);
             if (mine && ok) {
                 value = v;
                 n_noise += calls;

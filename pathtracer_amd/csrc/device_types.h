@@ -64,6 +64,10 @@ struct SceneDev {
     // big craters of every crater ball: 12 floats per crater {cell.xyz, size, on_sphere.xyz, t, age bits, 1/(5 size), -, -};
     // a ball's records start at record PrimRec::p[3] and number PrimRec::p[4] (both uint32 bit patterns)
     const float* craters;
+    // per crater ball, in the order of their tables: for each of the 9^3 lattice cells about floor(offset) - 4 that a
+    // query can fall into, the mask of table entries within the 4^3 cells the reference visits from there; the ball's
+    // ordinal sits above the low 8 bits of PrimRec::p[4]
+    const unsigned long long* crater_masks;
     // the raw noise transform (Linear row-major, then the translation), read by the SDF kinds that run noise() octave by octave
     const float* noise_raw;
     uint32_t plain_sdf;            // the scene holds SDF kinds evaluated one point per lane (RoughBoxObject)
