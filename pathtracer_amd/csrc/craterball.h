@@ -103,16 +103,30 @@ __device__ __forceinline__ uint32_t shl5(uint32_t h) {
 
 // One cell of for_each_nearby_scattered_point :79-116: hashed, jittered lattice point.  The reference
 // forms the jitter through double; fmaf(scatter/2, m, g) rounds the same exact value once.
-__device__ __forceinline__ f3 scattered_cell(f3 g, float half_scatter, uint32_t& hash) {
-    // Lattice coordinates and multipliers fit 24 signed bits, so the full-rate 24-bit multiply returns
-    // the same low 32 bits as the wrapping int multiply of the reference, and h * 31 = (h << 5) - h.
-    // Both are spelled in asm because the compiler folds the C forms back into quarter-rate v_mul_lo_u32.
-    uint32_t h = mul24_lo(static_cast<int>(g.x), 885889) + mul24_lo(static_cast<int>(g.y), 745273) + mul24_lo(static_cast<int>(g.z), 1220689);
+// Lattice coordinates and multipliers fit 24 signed bits, so the full-rate 24-bit multiply returns
+// the same low 32 bits as the wrapping int multiply of the reference, and h * 31 = (h << 5) - h.
+// Both are spelled in asm because the compiler folds the C forms back into quarter-rate v_mul_lo_u32.
+constexpr int kHashX = 885889, kHashY = 745273, kHashZ = 1220689;
+__device__ __forceinline__ uint32_t cell_hash_seed(f3 g) {   // the sum the four mixing rounds start from
+    return mul24_lo(static_cast<int>(g.x), kHashX) + mul24_lo(static_cast<int>(g.y), kHashY) + mul24_lo(static_cast<int>(g.z), kHashZ);
+}
+__device__ __forceinline__ uint32_t cell_hash_mix(uint32_t h) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         h |= (h & 0x0f0f0f0fu) << 4;
         h = shl5(h) - h;
     }
+    return h;
+}
+// The jittered point of a cell for scatter 1 (the small and tiny craters), given the cell minus one half:
+// g + 0.5 (m / 512 - 1) = (g - 0.5) + m / 1024, both sides exact before the one rounding of the fused
+// multiply-add, so this is scattered_cell(g, 0.5, .) bit for bit with three instructions fewer.
+__device__ __forceinline__ f3 jitter_unit(f3 g_minus_half, uint32_t h) {
+    return mk3(fmaf(static_cast<float>(h & 0x3ffu), 1.0f / 1024.0f, g_minus_half.x), fmaf(static_cast<float>((h >> 10) & 0x3ffu), 1.0f / 1024.0f, g_minus_half.y),
+               fmaf(static_cast<float>((h >> 20) & 0x3ffu), 1.0f / 1024.0f, g_minus_half.z));
+}
+__device__ __forceinline__ f3 scattered_cell(f3 g, float half_scatter, uint32_t& hash) {
+    const uint32_t h = cell_hash_mix(cell_hash_seed(g));
     hash = h;
     const float mx = fmaf(static_cast<float>(h & 0x3ffu), 1.0f / 512.0f, -1.0f);
     const float my = fmaf(static_cast<float>((h >> 10) & 0x3ffu), 1.0f / 512.0f, -1.0f);
@@ -198,27 +212,34 @@ __device__ __forceinline__ int fallout_fix(float n1, float n2, float lin, float 
 }
 
 // One cell of the small (scale 10, :412-437) or tiny (scale 60, :440-463) craters.
+// `seed` is cell_hash_seed(cell) and `cell_minus_half` the cell's lattice point minus 0.5 on every axis.
 struct MinorCell {
     bool pass;
     uint32_t age;
-    float th, size, c50;
+    float size, c50;
 };
-__device__ __forceinline__ MinorCell minor_cell(f3 q2, f3 cell, f3 off, float scale, bool tiny) {
+__device__ __forceinline__ MinorCell minor_cell(f3 q2, uint32_t seed, f3 cell_minus_half, f3 off, float scale, bool tiny) {
     MinorCell m;
-    uint32_t h2;
     f3 on2;
-    const f3 pt2 = scattered_cell(cell, 0.5f, h2);
+    const uint32_t h2 = cell_hash_mix(seed);
+    const f3 pt2 = jitter_unit(cell_minus_half, h2);
     m.pass = project_cell(pt2, off, scale, on2);
     const float t2 = static_cast<float>(h2 & 0xffffu) * (1.0f / 65535.0f);
     m.age = h2 >> 16;
     const float d2 = __builtin_amdgcn_sqrtf(fnorm2(q2 - on2));
     m.size = tiny ? fmaf(0.35f, t2, 0.02f) : fmaf(0.35f * t2, t2, 0.05f);
     m.c50 = 50.0f * (d2 - m.size);
-    m.th = fast_tanh(m.c50);
     return m;
 }
-__device__ __forceinline__ float small_term(const MinorCell& m) { return -0.005f * m.th; }
-__device__ __forceinline__ float tiny_term(const MinorCell& m) { return (-0.004f * m.size) * fmaf(0.5f, m.th, -0.5f); }
+// Small craters: `crater = max(crater, -0.005 tanh(c50))` over the cells that take effect is the term of the
+// smallest c50 among them (tanh rises with its argument), so one tanh per evaluation serves all eight cells.
+constexpr float kNoSmallCrater = 3.402823466e38f;   // "no cell took effect" as a c50
+__device__ __forceinline__ float small_total(float least_c50) { return least_c50 < kNoSmallCrater ? -0.005f * fast_tanh(least_c50) : -3.402823466e38f; }
+// Tiny craters: (-0.004 size) (0.5 tanh(c50) - 0.5).  From c50 = 10 on, fast_tanh returns exactly 1 (exp2 of
+// more than 28 leaves 2 / (e + 1) below a quarter of an ulp of 1) and the term exactly 0, which the running
+// maximum, starting from 0, ignores: such cells are skipped.
+constexpr float kTinyReach = 10.0f;
+__device__ __forceinline__ float tiny_term(const MinorCell& m) { return (-0.004f * m.size) * fmaf(0.5f, fast_tanh(m.c50), -0.5f); }
 
 __device__ __forceinline__ float near_total(float s, int big_fix, float crater_small, float tiny, int fallout, float nf1, float nf2) {
     const float crater = fmaxf(from_fix(big_fix), crater_small);
@@ -401,7 +422,8 @@ __device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, float4
     const bool tiny_lane = (lane & 8u) != 0u;
     const float scale = tiny_lane ? 60.0f : 10.0f;
     const f3 q2 = mk3(fmaf(ur.x, scale, offr.x), fmaf(ur.y, scale, offr.y), fmaf(ur.z, scale, offr.z));
-    const MinorCell mc = minor_cell(q2, mk3(floorf(q2.x) + cl.si, floorf(q2.y) + cl.sj, floorf(q2.z) + cl.sk), offr, scale, tiny_lane);
+    const f3 cell = mk3(floorf(q2.x) + cl.si, floorf(q2.y) + cl.sj, floorf(q2.z) + cl.sk);
+    const MinorCell mc = minor_cell(q2, cell_hash_seed(cell), mk3(cell.x - 0.5f, cell.y - 0.5f, cell.z - 0.5f), offr, scale, tiny_lane);
     // A small-crater cell takes effect iff it passes the shell and rim tests and its age does not exceed
     // the running minimum, which only cells that took effect lower: the running minimum before cell k is
     // min(min_age0, ages of the earlier candidates), an exclusive prefix minimum over lanes 0-7 of the row.
@@ -413,9 +435,9 @@ __device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, float4
     incl = min(incl, dpp_u<kRowShr4>(0xffffffffu, incl));
     const uint32_t excl = dpp_u<kRowShr1>(0xffffffffu, incl);
     const bool takes = cand && mc.age <= excl;
-    const float crater_small_r = row_max(takes ? small_term(mc) : -3.402823466e38f);
+    const float crater_small_r = small_total(-row_max(takes ? -mc.c50 : -kNoSmallCrater));   // the least c50 of the cells that take effect
     const uint32_t min_age1 = min(min_age_r, row_min_u(xa));
-    const bool tiny_ok = in_use && tiny_lane && mc.pass && mc.age <= min_age1;
+    const bool tiny_ok = in_use && tiny_lane && mc.pass && mc.age <= min_age1 && mc.c50 < kTinyReach;
     const float tiny_r = row_max(tiny_ok ? tiny_term(mc) : 0.0f);
 
     // ---- fallout and the final sum per point -----------------------------------------------
@@ -564,7 +586,7 @@ __device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, const
     }
 
     // ---- small and tiny craters, cell by cell in the reference's order --------------------------
-    float crater_small = -3.402823466e38f, tiny = 0.0f;
+    float least_c50 = kNoSmallCrater, tiny = 0.0f;
     if (active) {
 #pragma unroll 1
         for (int pass_no = 0; pass_no < 2; ++pass_no) {
@@ -572,21 +594,25 @@ __device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, const
             const float scale = is_tiny ? 60.0f : 10.0f;
             const f3 q2 = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
             const f3 f2 = mk3(floorf(q2.x), floorf(q2.y), floorf(q2.z));
+            const uint32_t seed0 = cell_hash_seed(f2);   // the neighbours' seeds differ from it by wave-uniform constants
 #pragma unroll 1
             for (int cell = 0; cell < 8; ++cell) {
-                const f3 g = mk3(f2.x + static_cast<float>(cell >> 2), f2.y + static_cast<float>((cell >> 1) & 1), f2.z + static_cast<float>(cell & 1));
-                const MinorCell mc = minor_cell(q2, g, off, scale, is_tiny);
+                const int dx = cell >> 2, dy = (cell >> 1) & 1, dz = cell & 1;
+                const uint32_t seed = seed0 + static_cast<uint32_t>(dx * kHashX + dy * kHashY + dz * kHashZ);
+                const f3 gm = mk3(f2.x + (dx ? 0.5f : -0.5f), f2.y + (dy ? 0.5f : -0.5f), f2.z + (dz ? 0.5f : -0.5f));
+                const MinorCell mc = minor_cell(q2, seed, gm, off, scale, is_tiny);
                 if (!is_tiny) {
                     if (mc.pass && mc.c50 < 0.0f && mc.age <= min_age) {
-                        crater_small = fmaxf(crater_small, small_term(mc));
+                        least_c50 = fminf(least_c50, mc.c50);
                         min_age = mc.age;
                     }
-                } else if (mc.pass && mc.age <= min_age) {
+                } else if (mc.pass && mc.age <= min_age && mc.c50 < kTinyReach) {
                     tiny = fmaxf(tiny, tiny_term(mc));
                 }
             }
         }
     }
+    const float crater_small = small_total(least_c50);
 
     // ---- remaining noise() calls, then fallout and the final sum ----------------------------------
     noise_ring_rounds(cl, lds, lane, done, staged, true);
