@@ -41,7 +41,7 @@ struct mipt_ctx {
     float* tm_scratch = nullptr;     // Reinhard partials
     float* stage = nullptr;          // staging for probes / host tone mapping
     size_t stage_cap = 0;
-    uint32_t lane_threshold = 24;   // MIPT_LANE_THRESHOLD: 1 = always one point per lane, 65 = never
+    uint32_t lane_threshold = 14;   // MIPT_LANE_THRESHOLD: 1 = always one point per lane, 65 = never
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // optional per-launch timing
