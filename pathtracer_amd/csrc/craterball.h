@@ -639,7 +639,18 @@ __device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, const
 // lanes wait, otherwise (and for the rare point lane_near leaves over) the whole wave works on groups
 // of four points, then on single points.
 // =============================================================================================
-__device__ __forceinline__ void wave_near(const float* crater_table, const unsigned long long* crater_masks, const CoopLane& cl, float* lds, uint32_t lane, uint32_t lane_threshold, bool wants,
+// A wave keeps the crater table of the ball it served last in registers (lane c holds crater c), so a march
+// that stays on one ball -- every march of a scene with one ball -- reads the table from memory once.
+struct CraterTableRegs {
+    float4 r0, r1;
+    float age_bits, inv_5size;   // the two fields of the third record that the evaluators use
+    uint32_t base;               // first record of the cached table, 0xffffffff: nothing cached
+};
+__device__ __forceinline__ CraterTableRegs no_crater_table() {
+    return CraterTableRegs{make_float4(1e30f, 1e30f, 1e30f, 1.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f), 0.0f, 1.0f, 0xffffffffu};
+}
+
+__device__ __forceinline__ void wave_near(const float* crater_table, const unsigned long long* crater_masks, CraterTableRegs& cache, const CoopLane& cl, float* lds, uint32_t lane, uint32_t lane_threshold, bool wants,
                                           f3 p, f3 off, float s, uint32_t crater_base, uint32_t crater_count, float& value, uint32_t& n_evals,
                                           uint32_t& n_noise) {
     unsigned long long todo = __ballot(wants);
@@ -653,13 +664,19 @@ __device__ __forceinline__ void wave_near(const float* crater_table, const unsig
         unsigned long long need = __ballot(mine);
         todo &= ~need;
         // lane c holds crater c of the ball's table; lanes past the table hold a cell out of anyone's reach
-        const float4* table = reinterpret_cast<const float4*>(crater_table) + 3u * base;
-        float4 r0 = make_float4(1e30f, 1e30f, 1e30f, 1.0f), r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r2 = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
-        if (lane < count) {
-            r0 = table[3u * lane];
-            r1 = table[3u * lane + 1u];
-            r2 = table[3u * lane + 2u];
+        if (cache.base != base) {
+            const float4* table = reinterpret_cast<const float4*>(crater_table) + 3u * base;
+            cache = no_crater_table();
+            cache.base = base;
+            if (lane < count) {
+                cache.r0 = table[3u * lane];
+                cache.r1 = table[3u * lane + 1u];
+                const float4 third = table[3u * lane + 2u];
+                cache.age_bits = third.x;
+                cache.inv_5size = third.y;
+            }
         }
+        const float4 r0 = cache.r0, r1 = cache.r1, r2 = make_float4(cache.age_bits, cache.inv_5size, 0.0f, 0.0f);
         if (static_cast<uint32_t>(__popcll(need)) >= lane_threshold) {
             float v = 0.0f;
             uint32_t calls = 0;

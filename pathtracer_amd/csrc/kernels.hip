@@ -838,6 +838,7 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
     const uint32_t lane = __lane_id();
     float* lds = s_coop + (threadIdx.x >> 6) * kNearLdsFloats;
     const CoopLane cl = make_coop_lane(sc.noise_oct, lane);
+    CraterTableRegs crater_regs = no_crater_table();
     March m;
     m.p = m.dir = mk3(0, 0, 0);
     m.d = 0.0f;
@@ -952,7 +953,7 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
         // (4) near-field evaluations for the crater-ball lanes that need one
         const bool wants = state == MARCH && result == 0 && !(PLAIN && plain);
         float d2 = 0.0f;
-        wave_near(sc.craters, sc.crater_masks, cl, lds, lane, bp.lane_threshold, wants, m.p, off, s, crater_base, crater_count, d2, c_near, c_noise);
+        wave_near(sc.craters, sc.crater_masks, crater_regs, cl, lds, lane, bp.lane_threshold, wants, m.p, off, s, crater_base, crater_count, d2, c_near, c_noise);
         if (wants) result = march_step(m, d2, ball_box);
         // (5) finished marches fold into the ray's best hit and move on to the next primitive
         if (state == MARCH && result != 0) {
@@ -1081,6 +1082,7 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
     const uint32_t lane = __lane_id();
     float* lds = s_near + (threadIdx.x >> 6) * kNearLdsFloats;
     const CoopLane cl = make_coop_lane(sc.noise_oct, lane);
+    CraterTableRegs crater_regs = no_crater_table();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t e = lane & 3u;   // which of the four points
     const float delta = 1e-3f;
@@ -1133,7 +1135,7 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
                 c_evals += 2;
             }
         }
-        wave_near(sc.craters, sc.crater_masks, cl, lds, lane, bp.lane_threshold, wants, p, off, s, crater_base, crater_count, v, c_near, c_noise);
+        wave_near(sc.craters, sc.crater_masks, crater_regs, cl, lds, lane, bp.lane_threshold, wants, p, off, s, crater_base, crater_count, v, c_near, c_noise);
         const float v0 = dpp_f<0x00>(0.0f, v), v1 = dpp_f<0x55>(0.0f, v), v2 = dpp_f<0xAA>(0.0f, v), v3 = dpp_f<0xFF>(0.0f, v);   // quad broadcasts
         bool alive = false;
         if (valid && e == 0u) {
