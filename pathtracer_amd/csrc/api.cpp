@@ -41,6 +41,7 @@ struct mipt_ctx {
     float* tm_scratch = nullptr;     // Reinhard partials
     float* stage = nullptr;          // staging for probes / host tone mapping
     size_t stage_cap = 0;
+    bool full_march = false;        // MIPT_FULL_MARCH=1: no shortcut for SDF marches that cannot end (for the equivalence test)
     uint32_t lane_threshold = 14;   // MIPT_LANE_THRESHOLD: 1 = always one point per lane, 65 = never
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -351,7 +352,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.height = st->height;
         bp.tiles_x = tiles_x;
         bp.first_sample = st->first_sample + done;
-        bp.flags = st->flags;
+        bp.flags = st->flags | (c->full_march ? kFlagFullMarch : 0u);
         bp.lane_threshold = c->lane_threshold;
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
@@ -442,6 +443,7 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
         *c->cancel_host = 0u;
         c->cancel_dev = static_cast<const volatile uint32_t*>(dev);
     }
+    if (const char* e = std::getenv("MIPT_FULL_MARCH")) c->full_march = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_LANE_THRESHOLD")) {
         const long v = std::atol(e);
         if (v >= 1 && v <= 65) c->lane_threshold = static_cast<uint32_t>(v);
@@ -835,7 +837,7 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     bp.n_pix = bp.n_slots = static_cast<uint32_t>(n);
     bp.width = width;
     bp.height = height;
-    bp.flags = MIPT_FLAG_NO_JITTER;
+    bp.flags = MIPT_FLAG_NO_JITTER | (c->full_march ? kFlagFullMarch : 0u);
     bp.lane_threshold = c->lane_threshold;
     mipt_camera c0 = *cam;
     c0.blur_radius = 0.0f;
@@ -881,6 +883,7 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     bp.width = n;
     bp.height = 1;
     bp.lane_threshold = c->lane_threshold;
+    bp.flags = c->full_march ? kFlagFullMarch : 0u;
     bp.seed = seed;
     HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
     launch_latch_cancel(c->stream, c->pb);

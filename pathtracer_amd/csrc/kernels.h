@@ -48,6 +48,8 @@ struct BatchParams {
 
 // Pixel rectangles (inclusive) outside of which no primary ray can reach anything: the screen bounds of
 // the scene's boxes.  Pixels outside all of them are not traced at all.
+constexpr uint32_t kFlagFullMarch = 0x80000000u;   // BatchParams::flags: SDF marches run out their 256 iterations (no shortcut for marches that cannot end)
+
 struct CullRects {
     int n;
     int r[8][4];   // x0, y0, x1, y1

@@ -267,7 +267,7 @@ def test_sdf_value_is_independent_of_evaluator():
     frames = []
     old = os.environ.get("MIPT_LANE_THRESHOLD")
     try:
-        for threshold in ("1", "65", "24"):
+        for threshold in ("1", "65", "14"):
             os.environ["MIPT_LANE_THRESHOLD"] = threshold
             c = api.Context()
             img, st = c.render(c.upload(flat), cam, 96, 96, 8, 8, seed=11)
@@ -283,6 +283,36 @@ def test_sdf_value_is_independent_of_evaluator():
         for key in ("rays", "sdf_rays", "sdf_shades", "sdf_near_evals", "sdf_far_evals", "sdf_noise_calls", "shade_noise_calls"):
             assert st[key] == frames[0][1][key], key
     assert frames[0][1]["sdf_near_evals"] > 10000
+
+
+def test_marches_that_cannot_end_are_cut_short_without_changing_the_frame(golden):
+    """A march whose state (p, d) stops changing, or comes back bit for bit, can only run out its 256 iterations
+    and miss (include/Object.hpp:135-167).  The kernels end it at once; with MIPT_FULL_MARCH=1 they run every
+    iteration as the reference does.  Frames, ray counts and SDF hits must be identical, evaluations fewer."""
+    import os
+    alg = api.HostAlgebra()
+    cases = [(S.demo_scene(alg), G.demo_closeup_camera(alg)),
+             (G.roughbox_scene(alg, golden["noise12"]), G.roughbox_camera(alg))]
+    old = os.environ.get("MIPT_FULL_MARCH")
+    try:
+        for flat, cam in cases:
+            frames = []
+            for full in ("1", "0"):
+                os.environ["MIPT_FULL_MARCH"] = full
+                c = api.Context()
+                img, st = c.render(c.upload(flat), cam, 96, 96, 8, 8, seed=11)
+                frames.append((img, st))
+                c.close()
+            (full_img, full_st), (img, st) = frames
+            assert np.array_equal(img, full_img)
+            for key in ("rays", "sdf_rays", "sdf_shades"):
+                assert st[key] == full_st[key], key
+            assert st["sdf_near_evals"] < 0.97 * full_st["sdf_near_evals"], (st["sdf_near_evals"], full_st["sdf_near_evals"])
+    finally:
+        if old is None:
+            os.environ.pop("MIPT_FULL_MARCH", None)
+        else:
+            os.environ["MIPT_FULL_MARCH"] = old
 
 
 def test_fractal_object_is_exact(ctx, alg, oracle, golden):
