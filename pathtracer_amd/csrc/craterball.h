@@ -249,59 +249,53 @@ __device__ __forceinline__ float near_total(float s, int big_fix, float crater_s
 // What each lane contributes to the cooperative parts of an evaluation.
 struct CoopLane {
     float si, sj, sk;   // lanes 0-7 / 8-15 of a row: cell of the 2^3 small / tiny-crater neighbourhood (0..1)
-    float m0, m1;       // this lane's element of the two octave matrices (below)
-    float kw0, kw1;     // weights of octaves (lane >> 4) and 4 + (lane >> 4)
+    float a_xy, a_z1;   // this lane's element of the two octave matrices (below)
+    float kw[4];        // weights of octaves (lane >> 5), 2 + (lane >> 5), 4 + ..., 6 + ...
 };
 
 // noise() :56-70 is 8 octaves; octave o samples the triangle wave at q_o = A_o p + b_o (the composed
-// affine, 13 floats per octave in `noise_oct`: A row-major, b + 0.25, weight).  For 16 points at once
-// that is a 32 x 4 by 4 x 16 matrix product -- rows (octave, coordinate) padded to 4 per octave, columns
-// (x, y, z, 1) -- which two v_mfma_f32_16x16x4_f32 compute exactly (f32 FMA chains) while the vector
-// pipe does other waves' work.  Lane l supplies element [l & 15][l >> 4] of each 16 x 4 tile.
+// affine, 13 floats per octave in `noise_oct`: A row-major, b + 0.25, weight).  For 32 points at once
+// that is a 32 x 4 by 4 x 32 matrix product -- rows (octave, coordinate) padded to 4 per octave, columns
+// (x, y, z, 1) -- which two chained v_mfma_f32_32x32x2_f32 compute exactly (f32 FMA chains, k = x, y,
+// then z, 1) while the vector pipe does other waves' work.  Lane l supplies element [l & 31][l >> 5] of
+// each 32 x 2 tile.
 __device__ __forceinline__ CoopLane make_coop_lane(const float* noise_oct, uint32_t lane) {
     CoopLane c;
     c.si = static_cast<float>((lane >> 2) & 1u);
     c.sj = static_cast<float>((lane >> 1) & 1u);
     c.sk = static_cast<float>(lane & 1u);
-    c.m0 = c.m1 = c.kw0 = c.kw1 = 0.0f;
+    c.a_xy = c.a_z1 = 0.0f;
+    c.kw[0] = c.kw[1] = c.kw[2] = c.kw[3] = 0.0f;
     if (!noise_oct) return c;   // a scene without crater balls carries no octave table (and never evaluates one)
-    const uint32_t row = lane & 15u, k = lane >> 4, coord = row & 3u;
+    const uint32_t row = lane & 31u, k = lane >> 5, octave = row >> 2, coord = row & 3u;
     if (coord < 3u) {
-        const uint32_t o0 = row >> 2, o1 = 4u + (row >> 2);
-        c.m0 = k < 3u ? noise_oct[13u * o0 + 3u * coord + k] : noise_oct[13u * o0 + 9u + coord];
-        c.m1 = k < 3u ? noise_oct[13u * o1 + 3u * coord + k] : noise_oct[13u * o1 + 9u + coord];
+        c.a_xy = noise_oct[13u * octave + 3u * coord + k];                                         // x or y coefficient
+        c.a_z1 = k == 0u ? noise_oct[13u * octave + 3u * coord + 2u] : noise_oct[13u * octave + 9u + coord];   // z coefficient or b + 0.25
     }
-    c.kw0 = noise_oct[13u * k + 12u];
-    c.kw1 = noise_oct[13u * (4u + k) + 12u];
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i) c.kw[i] = noise_oct[13u * (2u * i + k) + 12u];
     return c;
 }
 
-typedef float mipt_f32x4 __attribute__((ext_vector_type(4)));
+typedef float mipt_f32x16 __attribute__((ext_vector_type(16)));
 
-// noise() for 16 points at once: the matrix products, then the triangle waves and the sum over octaves.
-// `coord` is coordinate (lane >> 4) of point (lane & 15), and 1 on lanes 48-63; every lane gets the value
-// of point (lane & 15).  All 64 lanes must be active.
-struct Noise16 {
-    mipt_f32x4 q0, q1;   // q (+ 0.25) of octave (lane >> 4), resp. 4 + (lane >> 4), at point (lane & 15)
-};
-__device__ __forceinline__ Noise16 noise16_start(const CoopLane& cl, float coord) {
-    const mipt_f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    Noise16 n;
-    n.q0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cl.m0, coord, zero, 0, 0, 0);
-    n.q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cl.m1, coord, zero, 0, 0, 0);
-    return n;
-}
-__device__ __forceinline__ float noise16_finish(const CoopLane& cl, const Noise16& n) {
+// noise() for 32 points at once: the matrix products, then the triangle waves and the sum over octaves.
+// `c_xy` is x (lanes 0-31) or y (lanes 32-63) of point (lane & 31), `c_z1` is z (lanes 0-31) or 1; every
+// lane gets the value of point (lane & 31).  All 64 lanes must be active.  A lane holds, of its point,
+// q (+ 0.25) of octaves (lane >> 5) + 2 i in elements 4 i .. 4 i + 2.
+__device__ __forceinline__ float noise32(const CoopLane& cl, float c_xy, float c_z1) {
+    mipt_f32x16 q = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    q = __builtin_amdgcn_mfma_f32_32x32x2f32(cl.a_xy, c_xy, q, 0, 0, 0);
+    q = __builtin_amdgcn_mfma_f32_32x32x2f32(cl.a_z1, c_z1, q, 0, 0, 0);
     // triangle(v) = -1 + 4 |v - 0.25 - floor(v + 0.25)| = 4 |fract(v + 0.25) - 0.5| - 1  (:26-28)
-    const float a0 = (fabsf(__builtin_amdgcn_fractf(n.q0.x) - 0.5f) + fabsf(__builtin_amdgcn_fractf(n.q0.y) - 0.5f)) + fabsf(__builtin_amdgcn_fractf(n.q0.z) - 0.5f);
-    const float a1 = (fabsf(__builtin_amdgcn_fractf(n.q1.x) - 0.5f) + fabsf(__builtin_amdgcn_fractf(n.q1.y) - 0.5f)) + fabsf(__builtin_amdgcn_fractf(n.q1.z) - 0.5f);
-    float v = fmaf(cl.kw1, a1, cl.kw0 * a0);
-    // sum over the four rows of 16 lanes: rows 0+1 and 2+3, then the two halves
-    {
-        const unsigned u = __float_as_uint(v);
-        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    float v = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = (fabsf(__builtin_amdgcn_fractf(q[4 * i]) - 0.5f) + fabsf(__builtin_amdgcn_fractf(q[4 * i + 1]) - 0.5f)) +
+                        fabsf(__builtin_amdgcn_fractf(q[4 * i + 2]) - 0.5f);
+        v = i == 0 ? cl.kw[0] * a : fmaf(cl.kw[i], a, v);
     }
+    // even octaves on lanes 0-31, odd octaves on lanes 32-63: sum the two halves
     {
         const unsigned u = __float_as_uint(v);
         const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
@@ -327,7 +321,7 @@ __device__ __forceinline__ float noise16_finish(const CoopLane& cl, const Noise1
 // rounds, so the 256-step worst case of a march is a fraction of a millisecond.
 // =============================================================================================
 constexpr int kCoopGroup = 4;                                    // points one wave evaluates together
-constexpr int kCoopPts = 2 * 64 * kCoopGroup + 16;               // fallout points + final points, rounded up to whole rounds of 16
+constexpr int kCoopPts = 2 * 64 * kCoopGroup + 32;               // fallout points + final points, rounded up to whole rounds of 32
 constexpr int kCoopLdsFloats = 4 * kCoopPts;                     // x, y, z, value
 
 template <int G>
@@ -388,21 +382,22 @@ __device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, float4
     }
     wave_lds_fence();
 
-    // ---- noise(): 16 points per round ------------------------------------------------------------
+    // ---- noise(): 32 points per round ------------------------------------------------------------
     // (the next round's arguments are fetched before this round computes, so LDS latency stays hidden;
     // slots past n_pts hold stale data whose values are never used)
     {
-        const uint32_t plane = min(lane >> 4, 2u) * static_cast<uint32_t>(kCoopPts);   // x, y or z array of this lane's coordinate
-        const bool is_one = lane >= 48u;
-        uint32_t slot = lane & 15u;
-        float coord = lds[plane + slot];
-        for (uint32_t first = 0; first < n_pts; first += 16u) {
-            const uint32_t next = slot + 16u < static_cast<uint32_t>(kCoopPts) ? slot + 16u : slot;
-            const float next_coord = lds[plane + next];
-            const float v = noise16_finish(cl, noise16_start(cl, is_one ? 1.0f : coord));
-            if (lane < 16u) pv[slot] = v;
+        const bool upper = lane >= 32u;
+        const float* p_xy = upper ? py : px;
+        uint32_t slot = lane & 31u;
+        float c_xy = p_xy[slot], c_z = pz[slot];
+        for (uint32_t first = 0; first < n_pts; first += 32u) {
+            const uint32_t next = slot + 32u < static_cast<uint32_t>(kCoopPts) ? slot + 32u : slot;
+            const float n_xy = p_xy[next], n_z = pz[next];
+            const float v = noise32(cl, c_xy, upper ? 1.0f : c_z);
+            if (!upper) pv[slot] = v;
             slot = next;
-            coord = next_coord;
+            c_xy = n_xy;
+            c_z = n_z;
         }
     }
     wave_lds_fence();
@@ -470,22 +465,24 @@ constexpr int kNearLdsFloats = kLaneLdsFloats > kCoopLdsFloats ? kLaneLdsFloats 
 __device__ __forceinline__ void noise_ring_rounds(const CoopLane& cl, float* lds, uint32_t lane, uint32_t& done, uint32_t staged, bool flush_all) {
     wave_lds_fence();
     const uint32_t* rt = reinterpret_cast<const uint32_t*>(lds + 3 * kRing);
-    const uint32_t plane = min(lane >> 4, 2u) * static_cast<uint32_t>(kRing);   // x, y or z array of this lane's coordinate
-    const bool is_one = lane >= 48u;
-    // 16 calls per round; the next round's arguments are fetched before this round computes
-    uint32_t call = done + (lane & 15u);
+    const bool upper = lane >= 32u;
+    const float* r_xy = lds + (upper ? kRing : 0);   // x of the call on lanes 0-31, y on lanes 32-63
+    const float* r_z = lds + 2 * kRing;
+    // 32 calls per round; the next round's arguments are fetched before this round computes
+    uint32_t call = done + (lane & 31u);
     uint32_t slot = call & (kRing - 1);
-    float coord = lds[plane + slot];
+    float c_xy = r_xy[slot], c_z = r_z[slot];
     uint32_t target = rt[slot];
-    while (flush_all ? done < staged : done + 16u <= staged) {
-        const uint32_t next = (call + 16u) & (kRing - 1);
-        const float next_coord = lds[plane + next];
+    while (flush_all ? done < staged : done + 32u <= staged) {
+        const uint32_t next = (call + 32u) & (kRing - 1);
+        const float n_xy = r_xy[next], n_z = r_z[next];
         const uint32_t next_target = rt[next];
-        const float v = noise16_finish(cl, noise16_start(cl, is_one ? 1.0f : coord));
-        if (lane < 16u && call < staged) lds[target] = v;
-        done += 16u;
-        call += 16u;
-        coord = next_coord;
+        const float v = noise32(cl, c_xy, upper ? 1.0f : c_z);
+        if (!upper && call < staged) lds[target] = v;
+        done += 32u;
+        call += 32u;
+        c_xy = n_xy;
+        c_z = n_z;
         target = next_target;
     }
     if (done > staged) done = staged;
