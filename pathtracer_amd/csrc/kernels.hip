@@ -1103,7 +1103,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
 // the four points of one hit, so a wave shades 16 hits per round; the quad's first lane then deflects
 // the path.  Hits are dealt to waves round-robin so that a short queue spreads over all waves.
 template <bool PLAIN>
-__global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce, uint32_t max_bounces) {
+__device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, uint32_t max_bounces) {
     if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
     const uint32_t n = pb.counters[bounce].n_sdf_shade;
     uint32_t* next_queue = pb.queue[(bounce + 1) & 1];
@@ -1222,6 +1222,16 @@ __global__ void __launch_bounds__(256) k_shade_sdf(SceneDev sc, BatchParams bp, 
         wave_add_total(&pb.totals->shade_near_evals, c_evals);
         wave_add_total(&pb.totals->shade_noise_calls, c_noise);
     }
+}
+
+// Three waves per SIMD for the crater-ball instantiation (the register allocator would otherwise take one
+// register too many for that); the instantiation with the lane-evaluated kinds needs more and runs two.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_shade_sdf(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce,
+                                                                                           uint32_t max_bounces) {
+    shade_sdf_body<false>(sc, bp, pb, bounce, max_bounces);
+}
+__global__ void __launch_bounds__(256) k_shade_sdf_plain(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce, uint32_t max_bounces) {
+    shade_sdf_body<true>(sc, bp, pb, bounce, max_bounces);
 }
 
 __global__ void k_finish_batch(PathBuffers pb, uint32_t bounces, uint32_t n_slots) {
@@ -1446,8 +1456,8 @@ void launch_shade(hipStream_t st, const SceneDev& sc, const BatchParams& bp, con
 }
 
 void launch_shade_sdf(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, uint32_t max_bounces) {
-    if (sc.plain_sdf) hipLaunchKernelGGL(k_shade_sdf<true>, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce, max_bounces);
-    else hipLaunchKernelGGL(k_shade_sdf<false>, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce, max_bounces);
+    if (sc.plain_sdf) hipLaunchKernelGGL(k_shade_sdf_plain, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce, max_bounces);
+    else hipLaunchKernelGGL(k_shade_sdf, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce, max_bounces);
 }
 
 void launch_finish_batch(hipStream_t st, const PathBuffers& pb, uint32_t bounces, uint32_t n_slots) {
