@@ -592,7 +592,7 @@ __device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, const
             const f3 q2 = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
             const f3 f2 = mk3(floorf(q2.x), floorf(q2.y), floorf(q2.z));
             const uint32_t seed0 = cell_hash_seed(f2);   // the neighbours' seeds differ from it by wave-uniform constants
-#pragma unroll 1
+#pragma unroll 8
             for (int cell = 0; cell < 8; ++cell) {
                 const int dx = cell >> 2, dy = (cell >> 1) & 1, dz = cell & 1;
                 const uint32_t seed = seed0 + static_cast<uint32_t>(dx * kHashX + dy * kHashY + dz * kHashZ);
