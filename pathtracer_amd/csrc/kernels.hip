@@ -728,7 +728,9 @@ template <int STACK>
 __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
     if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
     __shared__ int s_stack[STACK * 256];
-    constexpr uint32_t kCap = 128;
+    // one atomic on the SDF queue's counter per `kCap` entries of a wave (that counter is one address for the
+    // whole chip): as many as the traversal stacks leave room for
+    constexpr uint32_t kCap = STACK <= 8 ? 1024 : STACK <= 24 ? 512 : STACK <= 40 ? 256 : 128;
     __shared__ uint32_t s_pend[4 * kCap];
     PendingQueue to_sdf{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u};
     const uint32_t n = pb.counters[bounce].n_live;
