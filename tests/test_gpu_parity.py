@@ -109,6 +109,45 @@ def test_primary_hits_demo_scene(close, ctx, alg, oracle, golden):
     assert np.abs(want_t - got_t)[both].max() <= 2e-4
 
 
+def test_two_crater_balls_in_one_scene(alg, oracle, golden):
+    """Two CraterBallObjects with different offsets (each has its own crater table and cell masks) side by side,
+    so that one wave marches rays of both: hits against the oracle within the crater-ball bars, and the frame is
+    the same whichever evaluator serves a point."""
+    import os
+    b = S.SceneBuilder(alg, golden["noise12"])
+    m = S.material(diffuse=1.0, specular=0.0, albedo=(0.5, 0.5, 0.5))
+    b.craterball((-8.0, 15.0, -6.5), m, S.translation(-0.55, 0.0, 0.0))
+    b.craterball((3.25, -1.5, 7.75), m, alg.affine_mul(S.translation(0.6, 0.1, 0.3), alg.affine_mul(S.linear_to_affine(alg.rotation("z", 0.8)), S.scale(1.2))))
+    b.box((6.0, 0.1, 6.0), S.material(diffuse=1.0, specular=0.0, albedo=(0.7, 0.7, 0.7)), S.translation(0.0, 1.0, 0.0))
+    b.box((2.0, 0.05, 2.0), S.material(diffuse=1.0, specular=0.0, emitted=(12.0, 11.0, 10.0)), S.translation(0.0, -4.0, 0.0))
+    flat = b.build()
+    cam = S.camera(S.translation(0.0, 0.0, -7.0), aspect=1.0, fov=6.0, focal=10.0, blur=0.0)
+    want_prim, want_t = oracle.scene(flat).primary_hits(cam, 96, 96)
+    assert (want_prim == 0).sum() > 500 and (want_prim == 1).sum() > 500
+    frames = []
+    old = os.environ.get("MIPT_LANE_THRESHOLD")
+    try:
+        for threshold in ("1", "65", "14"):
+            os.environ["MIPT_LANE_THRESHOLD"] = threshold
+            c = api.Context()
+            ds = c.upload(flat)
+            got_prim, got_t = c.primary_hits(ds, cam, 96, 96)
+            assert (want_prim != got_prim).mean() <= 0.005
+            both = (want_prim == got_prim) & (want_prim >= 0)
+            assert np.abs(want_t - got_t)[both].max() <= 3e-4   # the second ball is scaled by 1.2
+            frames.append(c.render(ds, cam, 64, 64, 6, 8, seed=3))
+            c.close()
+    finally:
+        if old is None:
+            os.environ.pop("MIPT_LANE_THRESHOLD", None)
+        else:
+            os.environ["MIPT_LANE_THRESHOLD"] = old
+    for img, st in frames[1:]:
+        assert np.array_equal(img, frames[0][0])
+        assert st["sdf_near_evals"] == frames[0][1]["sdf_near_evals"]
+    assert frames[0][1]["sdf_shades"] > 2000
+
+
 def _random_rays(n, seed, extent, inner):
     r = np.random.RandomState(seed)
     o = r.uniform(-extent, extent, (n, 3)).astype(np.float32)
