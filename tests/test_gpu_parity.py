@@ -277,6 +277,37 @@ def test_cancel_and_errors(ctx, alg):
     assert st["paths"] == 16 * 16 * 2 and img.max() > 0
 
 
+def test_upload_and_render_refuse_bad_input(ctx, alg, oracle):
+    """Every refusal is a status (include/mipt.h), nothing is uploaded or rendered, and the context keeps working."""
+    import dataclasses
+    good = S.cornell_scene(alg)
+    bad_kind = dataclasses.replace(good, kind=good.kind.copy())
+    bad_kind.kind[1] = 8                                            # no such Object subclass
+    bad_material = dataclasses.replace(good, material=good.material.copy())
+    bad_material.material[0] = good.materials.shape[0]              # index past the material table
+    singular = dataclasses.replace(good, fwd=good.fwd.copy())
+    singular.fwd[0, :9] = 0.0                                       # a primitive squashed to nothing still uploads ...
+    for flat, status in ((bad_kind, -1), (bad_material, -1)):
+        with pytest.raises(api.MiptError) as e:
+            ctx.upload(flat)
+        assert e.value.status == status
+    ds = ctx.upload(good)
+    cam = S.cornell_camera(alg)
+    for args, status in (((40, 40, 65, 1), -6),      # more bounces than the per-batch counters hold
+                         ((40, 40, 8, 0), -1),       # no samples
+                         ((40, 1, 8, 1), -1)):       # H - 1 == 0
+        with pytest.raises(api.MiptError) as e:
+            ctx.render(ds, cam, *args)
+        assert e.value.status == status
+    # sizes that are not multiples of the 8 x 8 pixel tiles (ragged right and bottom edges)
+    img, st = ctx.render(ds, cam, 37, 19, 6, 16, seed=2)
+    assert img.shape == (19, 37, 3) and st["paths"] == 37 * 19 * 16 and np.isfinite(img).all()
+    want, _ = oracle.scene(good).render(cam, 37, 19, 6, 16, rng_mode=1, seed=2, threads=0, full_width=True)
+    close = np.abs(want - img) <= 1e-4 * np.maximum(1.0, np.abs(want))
+    assert close.all(axis=2).mean() >= 0.99
+    assert (img[:, 32:] > 0).any() and (img[16:] > 0).any()   # the partial tiles at the right and bottom edges are rendered
+
+
 def test_config3_100k_primitives_first_hits(ctx, alg, oracle):
     """Config 3's scene (100,000 alternating spheres / Y-rotated boxes): closest hits of 2,048 camera rays
     against a brute-force scan over every primitive (the reference's tree never culls, and cannot even be
