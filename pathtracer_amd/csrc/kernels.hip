@@ -508,14 +508,30 @@ __device__ __forceinline__ void trav_run(const SceneDev& sc, Trav& t, int* stack
     }
 }
 
-// Does the ray reach any SDF primitive's box before its best analytic hit?
+// Can a ray that reaches the box of SDF primitive `prim` end in anything but a miss?  For a crater ball the
+// answer is no when the ray never comes within 0.6 of the ball's centre (local units): out there
+// CraterBallObject::signedDistance returns |p| - 0.5 > 0.1 (PathTracerDemo.cpp:362-366), so the march
+// (include/Object.hpp:135-167) only ever sees values above its 1e-4 hit threshold and none that changes sign
+// -- it walks out of the box, a miss.  The test allows 1e-3 for rounding in the ray's points.  Other kinds: yes.
+__device__ __forceinline__ bool sdf_prim_can_hit(const SceneDev& sc, uint32_t prim, f3 o, f3 d) {
+    const PrimRec* pr = sc.prims + prim;
+    if (pr->kind != 3u) return true;
+    const f3 lo = aff_pos(pr->inv, o), ld = lin_mul(pr->inv, d);
+    const float tc = fmaxf(-dot(lo, ld) / norm_sq(ld), 0.0f);   // closest approach to the centre, not behind the origin
+    const f3 c = mk3(fmaf(tc, ld.x, lo.x), fmaf(tc, ld.y, lo.y), fmaf(tc, ld.z, lo.z));
+    return !(norm_sq(c) > 0.601f * 0.601f);
+}
+
+// Does the ray reach any SDF primitive (its box, and for a crater ball its near field) before its best analytic hit?
 // (lo0, hi0 are the corners of sdf_boxes[0], which a kernel loads once for all its rays.)
-__device__ __forceinline__ bool reaches_sdf_box(const SceneDev& sc, f3 lo0, f3 hi0, f3 o, f3 inv_d, float limit) {
+// `shortcuts` off (MIPT_FULL_MARCH=1): the box alone decides, and the march finds the miss itself.
+__device__ __forceinline__ bool reaches_sdf_box(const SceneDev& sc, f3 lo0, f3 hi0, f3 o, f3 d, f3 inv_d, float limit, bool shortcuts) {
     if (sc.n_sdf == 0) return false;
     float tn;
     const float lo[3] = {lo0.x, lo0.y, lo0.z}, hi[3] = {hi0.x, hi0.y, hi0.z};
-    bool any = slab(o, inv_d, lo, hi, limit, tn);
-    for (uint32_t k = 1; k < sc.n_sdf; ++k) any = any || slab(o, inv_d, sc.sdf_boxes[k].lo, sc.sdf_boxes[k].hi, limit, tn);
+    bool any = slab(o, inv_d, lo, hi, limit, tn) && (!shortcuts || sdf_prim_can_hit(sc, sc.sdf_boxes[0].prim, o, d));
+    for (uint32_t k = 1; k < sc.n_sdf; ++k)
+        any = any || (slab(o, inv_d, sc.sdf_boxes[k].lo, sc.sdf_boxes[k].hi, limit, tn) && (!shortcuts || sdf_prim_can_hit(sc, sc.sdf_boxes[k].prim, o, d)));
     return any;
 }
 
@@ -693,7 +709,7 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
         const bool fin = trav_finished(t);
         bool keep = false, wants_sdf = false;
         if (fin) {
-            wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, t.o, t.inv_d, t.limit);
+            wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, t.o, t.d, t.inv_d, t.limit, !(bp.flags & kFlagFullMarch));
             keep = t.best != kMissKey || wants_sdf;
             if (keep) {
                 pb.ray_o[t.slot] = st4(t.o);
@@ -767,7 +783,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
         if (fin) {
             pb.hit_key[t.slot] = t.best;
             pb.hit_pos[t.slot] = st4(t.best_pos);
-            wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, t.o, t.inv_d, t.limit);
+            wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, t.o, t.d, t.inv_d, t.limit, !(bp.flags & kFlagFullMarch));
             t.busy = false;
         }
         pending_push(to_sdf, wants_sdf, t.slot, &pb.counters[bounce].n_sdf, pb.sdf_queue);

@@ -378,11 +378,14 @@ def test_sdf_value_is_independent_of_evaluator():
 
 def test_marches_that_cannot_end_are_cut_short_without_changing_the_frame(golden):
     """A march whose state (p, d) stops changing, or comes back bit for bit, can only run out its 256 iterations
-    and miss (include/Object.hpp:135-167).  The kernels end it at once; with MIPT_FULL_MARCH=1 they run every
-    iteration as the reference does.  Frames, ray counts and SDF hits must be identical, evaluations fewer."""
+    and miss (include/Object.hpp:135-167), and a ray that stays farther than 0.6 from a crater ball's centre only
+    ever sees the far field and walks out of the box.  The kernels return these misses at once; with
+    MIPT_FULL_MARCH=1 they march everything that enters a box, every iteration, as the reference does.  Frames,
+    ray counts and SDF hits must be identical, evaluations fewer."""
     import os
     alg = api.HostAlgebra()
-    cases = [(S.demo_scene(alg), G.demo_closeup_camera(alg)),
+    wide = S.camera(alg.affine_mul(S.translation(0.0, 0.0, -30.0), S.scale(0.01)), aspect=1.0, fov=3.5, focal=30.0, blur=0.0)   # ball and box corners in view
+    cases = [(S.demo_scene(alg), G.demo_closeup_camera(alg)), (S.demo_scene(alg), wide),
              (G.roughbox_scene(alg, golden["noise12"]), G.roughbox_camera(alg))]
     old = os.environ.get("MIPT_FULL_MARCH")
     try:
@@ -396,8 +399,9 @@ def test_marches_that_cannot_end_are_cut_short_without_changing_the_frame(golden
                 c.close()
             (full_img, full_st), (img, st) = frames
             assert np.array_equal(img, full_img)
-            for key in ("rays", "sdf_rays", "sdf_shades"):
+            for key in ("rays", "sdf_shades"):
                 assert st[key] == full_st[key], key
+            assert st["sdf_rays"] <= full_st["sdf_rays"]   # rays that cannot come near a crater ball are not marched at all
             assert st["sdf_near_evals"] < 0.97 * full_st["sdf_near_evals"], (st["sdf_near_evals"], full_st["sdf_near_evals"])
     finally:
         if old is None:
