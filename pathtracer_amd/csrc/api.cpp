@@ -732,7 +732,22 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
             s->cull_boxes.push_back(all);
         }
         if (sdf.size() <= 6) {
-            for (const SdfBox& b : sdf) s->cull_boxes.push_back({b.lo[0], b.lo[1], b.lo[2], b.hi[0], b.hi[1], b.hi[2]});
+            for (const SdfBox& b : sdf) {
+                std::array<float, 6> box{b.lo[0], b.lo[1], b.lo[2], b.hi[0], b.hi[1], b.hi[2]};
+                const PrimRec& r = prims[b.prim];
+                if (r.kind == MIPT_CRATERBALL) {
+                    // a ray that stays farther than 0.6 (local units) from the ball's centre can only miss (see
+                    // sdf_prim_can_hit in kernels.hip): the world box of that sphere is all a pixel needs to see
+                    for (int a = 0; a < 3; ++a) {
+                        const double row = std::sqrt(double(r.fwd[3 * a]) * r.fwd[3 * a] + double(r.fwd[3 * a + 1]) * r.fwd[3 * a + 1] +
+                                                     double(r.fwd[3 * a + 2]) * r.fwd[3 * a + 2]);
+                        const double half = 0.602 * row * 1.00001 + 1e-6;
+                        box[a] = std::max(box[a], static_cast<float>(r.fwd[9 + a] - half));
+                        box[3 + a] = std::min(box[3 + a], static_cast<float>(r.fwd[9 + a] + half));
+                    }
+                }
+                s->cull_boxes.push_back(box);
+            }
         } else {
             std::array<float, 6> m{big, big, big, -big, -big, -big};
             for (const SdfBox& b : sdf) grow(m, b.lo, b.hi);
