@@ -410,6 +410,35 @@ def test_marches_that_cannot_end_are_cut_short_without_changing_the_frame(golden
             os.environ["MIPT_FULL_MARCH"] = old
 
 
+def test_a_frame_in_several_sample_batches_equals_one_batch(alg):
+    """A frame whose paths do not fit the device at once is rendered in batches of whole samples (MIPT_BATCH_PATHS forces
+    that here): each batch adds its samples' sum to the frame, so only the order of float additions differs."""
+    import os
+    flat, cam = S.demo_scene(alg), G.demo_closeup_camera(alg)
+    w, h, spp = 64, 48, 24
+    old = os.environ.get("MIPT_BATCH_PATHS")
+    frames = []
+    try:
+        for budget in (None, 64 * 48 * 5):          # one batch; five batches of 5 samples (padded tiles: 64 x 48 = 48 tiles)
+            if budget is None:
+                os.environ.pop("MIPT_BATCH_PATHS", None)
+            else:
+                os.environ["MIPT_BATCH_PATHS"] = str(budget)
+            c = api.Context()
+            frames.append(c.render(c.upload(flat), cam, w, h, 8, spp, seed=5))
+            c.close()
+    finally:
+        if old is None:
+            os.environ.pop("MIPT_BATCH_PATHS", None)
+        else:
+            os.environ["MIPT_BATCH_PATHS"] = old
+    (one, st1), (many, st2) = frames
+    assert np.allclose(one, many, rtol=2e-6, atol=1e-7)
+    for key in ("paths", "rays", "sdf_rays", "sdf_shades", "sdf_near_evals", "primary_traced"):
+        assert st1[key] == st2[key], key
+    assert st1["sdf_shades"] > 1000
+
+
 def test_fractal_object_is_exact(ctx, alg, oracle, golden):
     """FractalObject (src/Object.cpp:160-252) is marched with exact arithmetic in the reference's order:
     primary hits equal the reference's fixture and the oracle bit for bit, traced paths and images with
