@@ -628,6 +628,13 @@ def test_present_rgba8_is_the_demo_display_step(ctx, alg):
     assert np.array_equal(got[..., :3], (np.clip(mapped, 0.0, 1.0) * np.float32(255.0)).astype(np.uint8))
     full, _ = ctx.render(ds, cam, w, h, 6, 12, seed=1)
     assert np.allclose(mean, full, rtol=1e-5, atol=1e-6)
+    # the tone mappers on device buffers (what the multi-GPU path uses after its all-reduce) equal the host-buffer calls
+    hdr = torch.from_numpy(mean).cuda()
+    ldr = torch.empty_like(hdr)
+    torch.cuda.synchronize()
+    for kind in (0, 1):
+        ctx.tonemap_device(kind, hdr.data_ptr(), ldr.data_ptr(), w, h)
+        assert np.array_equal(ldr.cpu().numpy(), ctx.tonemap(kind, mean))
 
 
 def test_config4_1m_primitives_first_hits(ctx, alg, oracle):
