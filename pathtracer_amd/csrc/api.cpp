@@ -805,6 +805,7 @@ int mipt_render(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
 
 int mipt_scale_device(mipt_ctx* c, const float* in, float k, size_t n, float* out) {
     if (!c || !in || !out) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);
     HIP_TRY(c, hipSetDevice(c->device));
     launch_scale(c->stream, in, k, n, out);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -931,6 +932,7 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
 
 int mipt_tonemap_device(mipt_ctx* c, int kind, const float* in, float* out, size_t width, size_t height) {
     if (!c || !in || !out || width == 0 || height == 0 || (kind != 0 && kind != 1)) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);   // the Reinhard scratch buffer and the stream belong to the context
     HIP_TRY(c, hipSetDevice(c->device));
     if (kind == 1) launch_tonemap_filmic(c->stream, in, out, width * height * 3);
     else launch_tonemap_reinhard(c->stream, in, out, width, height, c->tm_scratch, reinhard_scratch_floats());
