@@ -1,0 +1,34 @@
+"""bench.py prints one JSON line with the keys its contract names (run here on a small frame)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "180",
+                        "--spp", "32", "--cpu-spp", "1"], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in out, key
+    assert out["unit"] == "Mpaths/s" and out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["vs_baseline"] is None and out["data"] == "synthetic"
+    assert "workload" in out["config"] and "model" not in out["config"]
+    assert out["value"] > 0 and abs(out["value"] - 320 * 180 * 32 / (out["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * out["value"]
+    roof = out["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["kernel"] == "k_sdf_march" and roof["peak"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    cpu = out["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
