@@ -225,6 +225,15 @@ def main():
         out["cpu_baseline"] = {"value": cst["paths"] / cpu_s / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
                                "sample": f"same scene and camera, {W}x{H}, {a.cpu_spp} spp ({cst['paths']} paths, {cpu_s:.1f} s)",
                                "mrays_per_s": cst["rays"] / cpu_s / 1e6}
+        if orc.fast_lib() is not None:
+            # the same restatement compiled with -ffast-math (the reference's MSVC build sets /fp:fast), on half the sample
+            fspp = max(1, a.cpu_spp // 2)
+            fsc = orc.Oracle(fast_math=True).scene(flat)
+            t2 = time.perf_counter()
+            _, fst = fsc.render(cam, W, H, a.bounces, fspp, rng_mode=orc.RNG_MINSTD, seed=1, threads=cores, full_width=False)
+            fast_s = time.perf_counter() - t2
+            out["cpu_baseline"]["fast_math_value"] = fst["paths"] / fast_s / 1e6
+            out["cpu_baseline"]["fast_math_sample"] = f"{fspp} spp ({fast_s:.1f} s), g++ -O3 -ffast-math"
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

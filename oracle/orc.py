@@ -24,7 +24,7 @@ SPHERE, BOX, TRIANGLE, CRATERBALL = 0, 1, 2, 3
 
 def build(ref=True):
     """Compile liboracle.so and, when the reference checkout is present, _ref/libref.so."""
-    subprocess.run(["make", "-C", _HERE, "liboracle.so"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", _HERE, "liboracle.so", "liboracle_fast.so"], check=True, stdout=subprocess.DEVNULL)
     if ref and os.path.isdir("/root/reference/src"):
         subprocess.run(["make", "-C", _HERE, "ref"], check=True, stdout=subprocess.DEVNULL)
 
@@ -56,6 +56,20 @@ def lib():
         _lib.orc_scene_create.restype = C.c_void_p
         _lib.orc_counter_uniform01.restype = C.c_float
     return _lib
+
+
+_fast = None
+
+
+def fast_lib():
+    """liboracle_fast.so (the restatement compiled with -ffast-math: a timing baseline, not an oracle), or None."""
+    global _fast
+    if _fast is None:
+        _fast = _load(os.path.join(_HERE, "liboracle_fast.so"))
+        if _fast is not None:
+            _fast.orc_scene_create.restype = C.c_void_p
+            _fast.orc_counter_uniform01.restype = C.c_float
+    return _fast
 
 
 def ref():
@@ -120,10 +134,13 @@ class _Api:
 
 
 class Oracle(_Api):
-    """liboracle.so."""
+    """liboracle.so; with fast_math=True the -ffast-math build (for timing only)."""
 
-    def __init__(self):
-        super().__init__(lib(), "orc_")
+    def __init__(self, fast_math=False):
+        dll = fast_lib() if fast_math else lib()
+        if dll is None:
+            raise RuntimeError("oracle/liboracle_fast.so missing: run `make -C oracle`")
+        super().__init__(dll, "orc_")
 
     def scene(self, s):
         return OracleScene(self, s)
