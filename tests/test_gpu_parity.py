@@ -670,8 +670,11 @@ def test_cancel_drains_a_running_frame(alg):
     full_s = time.perf_counter() - t0
     result = {}
 
+    started = threading.Event()
+
     def work():
         t1 = time.perf_counter()
+        started.set()
         try:
             c.render(ds, cam, 1920, 1080, 8, 128, seed=1)
             result["status"] = 0
@@ -681,7 +684,8 @@ def test_cancel_drains_a_running_frame(alg):
 
     th = threading.Thread(target=work)
     th.start()
-    time.sleep(0.05)
+    started.wait()
+    time.sleep(0.05)                                     # the call has long begun (it clears a cancel that precedes it)
     c.cancel()
     th.join()
     assert result["status"] == capi.ERR_CANCELLED
