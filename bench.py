@@ -200,8 +200,19 @@ def main():
         n_launch = max(1, launches["sdf_march"])
         avg_ms = stage_ms["sdf_march"] / n_launch
         achieved = flops / n_launch / (avg_ms * 1e-3) / 1e12
+        # HBM bytes per launch of this kernel: a process cannot collect counters on itself, so the figure comes from
+        # the committed counter passes of this very command (FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs),
+        # and only when the workload is the one they were taken on
+        traffic, traffic_source = None, None
+        hbm_csv = os.path.join(ROOT, "profiles", "r01_pmc_hbm_demo1080p_1024spp.csv")
+        if a.scene == "demo" and (W, H, a.spp, a.bounces, world) == (1920, 1080, 1024, 8, 1) and os.path.exists(hbm_csv):
+            for line in open(hbm_csv):
+                if "k_sdf_march" in line:
+                    cols = line.strip().rsplit(",", 3)
+                    traffic = (float(cols[2]) + float(cols[3])) * 1024.0 / max(1.0, float(cols[1]))
+                    traffic_source = "profiles/r01_pmc_hbm_demo1080p_1024spp.csv (raw FETCH_SIZE + WRITE_SIZE, KB, per launch)"
         out["roofline"] = {"kernel": "k_sdf_march", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS,
-                           "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": None,
+                           "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                            "avg_launch_ms": avg_ms, "launches": n_launch,
                            "note": "fp32 vector peak; the octave transforms of noise() run on the f32 matrix core, whose peak is the same 157.3; "
                                    "flops = far*12 + near*6080 + noise*376 (the reference's arithmetic)"}
