@@ -3,8 +3,8 @@
 
 The reference draws from minstd_rand0 and the device from its counter generator, so only statistics
 can agree.  Acceptance: RMSE(GPU, ref A) <= 1.25 x RMSE(ref A, ref B), the
-reference's own seed-to-seed noise floor, and the mean relative error of the 8x8 box-filtered images
-<= 2 %."""
+reference's own seed-to-seed noise floor, and (at 4 x N on the device) the mean relative error of the
+8x8 box-filtered images <= 2 % and the whole-image mean within 1 %."""
 import os
 
 import numpy as np
@@ -21,6 +21,9 @@ CASES = {
     "cornell": (lambda a, n: S.cornell_scene(a), lambda a: S.cornell_camera(a)),
     "mixed": (lambda a, n: G.mixed_scene(a), lambda a: G.parity_camera(a, 4.0 / 3.0)),
     "demo_close": (lambda a, n: S.demo_scene(a, n), lambda a: G.demo_closeup_camera(a)),
+    "roughbox": (lambda a, n: G.roughbox_scene(a, n), lambda a: G.roughbox_camera(a)),
+    "roughsphere": (lambda a, n: G.roughsphere_scene(a, n), lambda a: G.sdf_camera(a, -8.0, 14.0)),
+    "weirdwall": (lambda a, n: G.weirdwall_scene(a, n), lambda a: G.sdf_camera(a, -14.0, 20.0, -0.5)),
 }
 
 
@@ -44,6 +47,12 @@ def test_converged_image_matches_reference_renderer(name):
     assert floor > 0
     assert rmse(got, a) <= 1.25 * floor, (rmse(got, a), floor)
     assert rmse(got, b) <= 1.25 * floor, (rmse(got, b), floor)
-    ref_mean = 0.5 * (_box(a) + _box(b))
-    rel = np.abs(_box(got) - ref_mean).mean() / ref_mean.mean()
+    # The box statistic looks for bias, so the device's own noise is cut with 4x the samples.  Where two
+    # reference seeds leave more than the bound in noise themselves, the fixture holds the mean over nine.
+    ctx = api.Context()
+    fine, _ = ctx.render(ctx.upload(mk_scene(alg, z["noise12"])), mk_cam(alg), w, h, bounces, 4 * spp, seed=78)
+    ctx.close()
+    ref_mean = _box(z[name + "_m"]) if name + "_m" in z.files else 0.5 * (_box(a) + _box(b))
+    rel = np.abs(_box(fine) - ref_mean).mean() / ref_mean.mean()
     assert rel <= 0.02, rel
+    assert abs(float(fine.mean()) / float(ref_mean.mean()) - 1.0) <= 0.01
