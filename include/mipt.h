@@ -145,6 +145,12 @@ const char* mipt_strerror(int status);
  * makeTree, src/ObjectTree.cpp:90-184; any topology returns the same closest hit because the
  * reference's tree never culls). */
 int  mipt_scene_upload(mipt_ctx*, const mipt_scene_desc*, mipt_scene** out);
+/* The same with build options.  MIPT_UPLOAD_DEVICE_BVH builds the tree on the GPU (Morton order + radix tree, a few
+ * launches) instead of on the host (binned surface-area heuristic): for scenes whose objects move every frame, where
+ * the host build (0.5 s at 100,000 objects) would dominate.  Frames are identical; rays cost somewhat more in the
+ * GPU-built tree.  MIPT_DEVICE_BVH=1 in the environment makes it the default of mipt_scene_upload. */
+enum { MIPT_UPLOAD_DEVICE_BVH = 1u };
+int  mipt_scene_upload_ex(mipt_ctx*, const mipt_scene_desc*, uint32_t flags, mipt_scene** out);
 void mipt_scene_free(mipt_scene*);
 /* BVH facts for tests and reports: out4 = node count, depth, analytic primitives, SDF primitives. */
 int  mipt_scene_info(const mipt_scene*, uint32_t out4[4]);

@@ -61,8 +61,11 @@ class HostAlgebra:
         return out
 
 
+UPLOAD_DEVICE_BVH = 1
+
+
 class DeviceScene:
-    def __init__(self, ctx, flat):
+    def __init__(self, ctx, flat, flags=None):
         self.ctx = ctx
         self._keep = [np.ascontiguousarray(flat.kind, np.uint32), f32(flat.fwd), f32(flat.inv), f32(flat.params),
                       np.ascontiguousarray(flat.material, np.uint32), f32(flat.materials), f32(flat.noise)]
@@ -70,7 +73,10 @@ class DeviceScene:
         d = capi.SceneDesc(k.shape[0], k.ctypes.data_as(capi._u32p), fp(fwd), fp(inv), fp(par),
                            mat.ctypes.data_as(capi._u32p), mats.shape[0], fp(mats), fp(noise))
         h = C.c_void_p()
-        check(capi.dll().mipt_scene_upload(ctx.h, C.byref(d), C.byref(h)), "mipt_scene_upload")
+        if flags is None:
+            check(capi.dll().mipt_scene_upload(ctx.h, C.byref(d), C.byref(h)), "mipt_scene_upload")
+        else:
+            check(capi.dll().mipt_scene_upload_ex(ctx.h, C.byref(d), int(flags), C.byref(h)), "mipt_scene_upload_ex")
         self.h = h
 
     def info(self):
@@ -107,8 +113,9 @@ class Context:
         except Exception:   # noqa: BLE001
             pass
 
-    def upload(self, flat):
-        return DeviceScene(self, flat)
+    def upload(self, flat, device_bvh=None):
+        """device_bvh: None = the library's default (host build unless MIPT_DEVICE_BVH=1), True/False = explicit."""
+        return DeviceScene(self, flat, None if device_bvh is None else (UPLOAD_DEVICE_BVH if device_bvh else 0))
 
     def set_profiling(self, on):
         check(capi.dll().mipt_set_profiling(self.h, 1 if on else 0), "mipt_set_profiling")

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "bvh.h"
+#include "lbvh.h"
 #include "device_types.h"
 #include "hostmath.h"
 #include "kernels.h"
@@ -41,6 +42,7 @@ struct mipt_ctx {
     float* tm_scratch = nullptr;     // Reinhard partials
     float* stage = nullptr;          // staging for probes / host tone mapping
     size_t stage_cap = 0;
+    bool device_bvh = false;        // MIPT_DEVICE_BVH=1: mipt_scene_upload builds the tree on the GPU
     bool full_march = false;        // MIPT_FULL_MARCH=1: no shortcut for SDF marches that cannot end (for the equivalence test)
     uint32_t lane_threshold = 14;   // MIPT_LANE_THRESHOLD: 1 = always one point per lane, 65 = never
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -444,6 +446,7 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
         c->cancel_dev = static_cast<const volatile uint32_t*>(dev);
     }
     if (const char* e = std::getenv("MIPT_FULL_MARCH")) c->full_march = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_DEVICE_BVH")) c->device_bvh = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_LANE_THRESHOLD")) {
         const long v = std::atol(e);
         if (v >= 1 && v <= 65) c->lane_threshold = static_cast<uint32_t>(v);
@@ -499,7 +502,11 @@ const char* mipt_strerror(int s) {
 }
 
 int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
-    if (!c || !d || !out) return MIPT_ERR_ARGUMENT;
+    return mipt_scene_upload_ex(c, d, c && c->device_bvh ? MIPT_UPLOAD_DEVICE_BVH : 0u, out);
+}
+
+int mipt_scene_upload_ex(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags, mipt_scene** out) {
+    if (!c || !d || !out || (flags & ~static_cast<uint32_t>(MIPT_UPLOAD_DEVICE_BVH))) return MIPT_ERR_ARGUMENT;
     *out = nullptr;
     if (d->n_prims == 0 || !d->kind || !d->fwd || !d->inv || !d->params || !d->material || !d->materials || d->n_materials == 0)
         return MIPT_ERR_ARGUMENT;
@@ -593,7 +600,22 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
             }
         analytic_boxes.push_back(u);
     }
-    BvhResult bvh = build_bvh(std::move(boxes));
+    BvhResult bvh;
+    void* d_lbvh = nullptr;   // nodes built on the device (owned by the scene once it exists)
+    if ((flags & MIPT_UPLOAD_DEVICE_BVH) && n_analytic >= 2) {
+        const hipError_t be = build_lbvh_device(c->stream, boxes.data(), n_analytic, analytic_boxes[0].data(), analytic_boxes[0].data() + 3, &d_lbvh, &bvh.depth);
+        if (be != hipSuccess) {
+            c->last_hip = static_cast<int>(be);
+            return be == hipErrorOutOfMemory ? MIPT_ERR_OUT_OF_MEMORY : MIPT_ERR_HIP;
+        }
+        if (bvh.depth < 1 || bvh.depth > 60) {   // the traversal stack holds 60 levels; only a great many coincident boxes get there
+            (void)hipFree(d_lbvh);
+            return MIPT_ERR_TOO_LARGE;
+        }
+    } else {
+        bvh = build_bvh(std::move(boxes));
+    }
+    const uint32_t n_nodes = d_lbvh ? n_analytic - 1u : static_cast<uint32_t>(bvh.nodes.size());
 
     // Big craters of each crater ball (for_each_nearby_scattered_point at scale 2, PathTracerDemo.cpp:375-409):
     // which lattice cells pass the shell test depends on the ball's offset alone.  The device evaluates the
@@ -605,7 +627,11 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
         constexpr int kCube = 9;
         constexpr size_t kCells = size_t(kCube) * kCube * kCube;
         float* d_cells = nullptr;
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_cells), kCells * 12 * sizeof(float)));
+        if (const hipError_t me = hipMalloc(reinterpret_cast<void**>(&d_cells), kCells * 12 * sizeof(float)); me != hipSuccess) {
+            if (d_lbvh) (void)hipFree(d_lbvh);
+            c->last_hip = static_cast<int>(me);
+            return MIPT_ERR_HIP;
+        }
         std::vector<float> cells(kCells * 12);
         for (const SdfBox& sb : sdf) {
             PrimRec& r = prims[sb.prim];
@@ -614,6 +640,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
             for (int a = 0; a < 3; ++a) {
                 if (!(std::fabs(r.p[a]) < 4.0e6f)) {   // lattice coordinates must stay exact 24-bit integers
                     (void)hipFree(d_cells);
+                    if (d_lbvh) (void)hipFree(d_lbvh);
                     return MIPT_ERR_ARGUMENT;
                 }
                 base[a] = static_cast<int>(std::floor(r.p[a])) - 4;
@@ -623,6 +650,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
             if (ce == hipSuccess) ce = hipStreamSynchronize(c->stream);
             if (ce != hipSuccess) {
                 (void)hipFree(d_cells);
+                if (d_lbvh) (void)hipFree(d_lbvh);
                 c->last_hip = static_cast<int>(ce);
                 return MIPT_ERR_HIP;
             }
@@ -632,6 +660,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
             const uint32_t count = static_cast<uint32_t>(craters.size() / 12) - first;
             if (count > 64) {   // one crater per lane; the shell holds ~32 cells for any offset (23..39 seen)
                 (void)hipFree(d_cells);
+                if (d_lbvh) (void)hipFree(d_lbvh);
                 return MIPT_ERR_TOO_LARGE;
             }
             // cell -> crater mask: crater c is visited from a query in cell f iff cell_c - f is -1, 0, 1 or 2 on every
@@ -658,8 +687,12 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     }
 
     auto* s = new (std::nothrow) mipt_scene;
-    if (!s) return MIPT_ERR_OUT_OF_MEMORY;
+    if (!s) {
+        if (d_lbvh) (void)hipFree(d_lbvh);
+        return MIPT_ERR_OUT_OF_MEMORY;
+    }
     s->device = c->device;
+    s->d_nodes = d_lbvh;
     auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
         if (bytes == 0) return hipSuccess;
         hipError_t e = hipMalloc(dst, bytes);
@@ -669,7 +702,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
     hipError_t e = upload(&s->d_prims, prims.data(), prims.size() * sizeof(PrimRec));
     if (e == hipSuccess) e = upload(&s->d_tri, tri_c.data(), tri_c.size() * sizeof(float));
     if (e == hipSuccess) e = upload(&s->d_mats, mats.data(), mats.size() * sizeof(MaterialRec));
-    if (e == hipSuccess) e = upload(&s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode));
+    if (e == hipSuccess && !d_lbvh) e = upload(&s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode));
     if (e == hipSuccess) e = upload(&s->d_sdf, sdf.data(), sdf.size() * sizeof(SdfBox));
     // noise() (PathTracerDemo.cpp:56-70) applies the transform T = (L, t), samples, scales by 1.1 and
     // repeats; octave i therefore samples q_i = A_i p + b_i with A_0 = L, b_0 = t, A_i = 1.1 L A_{i-1},
@@ -754,7 +787,7 @@ int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
             s->cull_boxes.push_back(m);
         }
     }
-    s->n_nodes = static_cast<uint32_t>(bvh.nodes.size());
+    s->n_nodes = n_nodes;
     s->n_analytic = n_analytic;
     s->n_sdf = static_cast<uint32_t>(sdf.size());
     s->depth = bvh.depth;

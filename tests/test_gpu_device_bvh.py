@@ -1,0 +1,106 @@
+"""The tree built on the GPU (mipt_scene_upload_ex with MIPT_UPLOAD_DEVICE_BVH) against the host-built one and
+the oracle's scan over every primitive.  The reference's tree never culls (src/ObjectTree.cpp:22-63), so the
+closest hit does not depend on the topology: indices, distances and whole frames must be bit-identical."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import golden_cases as G
+from pathtracer_amd import api, scene as S
+
+pytestmark = pytest.mark.gpu
+
+FIXTURE = os.path.join(os.path.dirname(__file__), "golden", "reference_cases.npz")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context()
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def alg():
+    return api.HostAlgebra()
+
+
+SCENES = {
+    "sphere_box": (lambda a: G.sphere_box_scene(a), lambda a: G.parity_camera(a), 96, 96),
+    "mixed": (lambda a: G.mixed_scene(a), lambda a: G.parity_camera(a, 4.0 / 3.0), 96, 72),
+    "cornell": (lambda a: S.cornell_scene(a), lambda a: S.cornell_camera(a), 64, 64),
+    "random2000": (lambda a: S.random_scene(a, 2000, seed=3, radius_scale=4.0), lambda a: S.random_scene_camera(a, aspect=1.0), 192, 192),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_primary_hits_do_not_depend_on_the_builder(name, ctx, alg, oracle):
+    mk_scene, mk_cam, w, h = SCENES[name]
+    flat, cam = mk_scene(alg), mk_cam(alg)
+    dev = ctx.upload(flat, device_bvh=True)
+    info = dev.info()
+    assert info["nodes"] == max(1, info["analytic"] - 1) and 1 <= info["depth"] <= 60
+    got_prim, got_t = ctx.primary_hits(dev, cam, w, h)
+    want_prim, want_t = oracle.scene(flat).primary_hits(cam, w, h)
+    assert np.array_equal(want_prim, got_prim), f"{np.sum(want_prim != got_prim)} primitive indices differ"
+    assert np.array_equal(want_t, got_t)
+    host_prim, host_t = ctx.primary_hits(ctx.upload(flat, device_bvh=False), cam, w, h)
+    assert np.array_equal(host_prim, got_prim) and np.array_equal(host_t, got_t)
+    assert (want_prim >= 0).mean() > 0.2
+
+
+def test_frames_do_not_depend_on_the_builder(ctx, alg):
+    """Whole frames with bounces, glass and mirrors, and with an SDF object beside the analytic ones: identical
+    bit for bit."""
+    noise = np.load(FIXTURE, allow_pickle=False)["out_noise12"]
+    for flat, cam, w, h, bounces, spp in (
+        (S.random_scene(alg, 900, seed=9, radius_scale=7.0, glass_mirror_mix=True), S.random_scene_camera(alg, aspect=1.0), 64, 64, 16, 8),
+        (S.demo_scene(alg, noise), G.demo_closeup_camera(alg), 48, 48, 6, 4),
+    ):
+        a, sa = ctx.render(ctx.upload(flat, device_bvh=False), cam, w, h, bounces, spp, seed=4)
+        b, sb = ctx.render(ctx.upload(flat, device_bvh=True), cam, w, h, bounces, spp, seed=4)
+        assert np.array_equal(a, b)
+        assert sa["rays"] == sb["rays"] and sa["rays"] > sa["paths"]
+
+
+def test_coincident_and_degenerate_boxes(ctx, alg, oracle):
+    """Many objects at one place (equal Morton codes), and a scene flat in one axis (zero extent)."""
+    flat = S.random_scene(alg, 300, seed=5, radius_scale=4.0)
+    flat.fwd[:200] = flat.fwd[0]          # 200 objects share one transform: same centre, same code
+    flat.fwd[200:, 10] = flat.fwd[200, 10]   # the rest in one horizontal plane
+    flat.inv[:] = alg.affine_inverse_batch(flat.fwd)
+    cam = S.random_scene_camera(alg, aspect=1.0)
+    dev = ctx.upload(flat, device_bvh=True)
+    assert dev.info()["depth"] <= 60
+    got_prim, got_t = ctx.primary_hits(dev, cam, 128, 128)
+    want_prim, want_t = oracle.scene(flat).primary_hits(cam, 128, 128)
+    assert np.array_equal(want_prim, got_prim) and np.array_equal(want_t, got_t)
+    assert (want_prim >= 0).any()
+
+
+def test_100k_primitives_device_build_is_fast_and_exact(ctx, alg, oracle):
+    flat = S.random_scene(alg, 100_000, seed=7)
+    cam = S.random_scene_camera(alg)
+    r = np.random.RandomState(12)
+    sx, sy = r.uniform(0, 1, 2048).astype(np.float32), r.uniform(0, 1, 2048).astype(np.float32)
+    d, o = oracle.camera_rays(cam, sx, sy, rng_mode=1, seed=1)
+    ctx.upload(flat, device_bvh=True).free()   # first use pays for loading the kernels
+    t0 = time.perf_counter()
+    dev = ctx.upload(flat, device_bvh=True)
+    t_dev = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    host = ctx.upload(flat, device_bvh=False)
+    t_host = time.perf_counter() - t0
+    info = dev.info()
+    assert info["analytic"] == 100_000 and info["nodes"] == 99_999 and 17 <= info["depth"] <= 60
+    print(f"upload of 100,000 primitives: device build {t_dev * 1e3:.1f} ms, host build {t_host * 1e3:.1f} ms, depths {info['depth']} / {host.info()['depth']}")
+    assert t_dev < t_host
+    _, prim, t = ctx.trace_rays(dev, o, d, 1, seed=1, first_hit=True)
+    wp, wt, _ = oracle.scene(flat).closest_hit(o, d)
+    assert np.array_equal(wp, prim)
+    assert np.array_equal(wt[wp >= 0], t[wp >= 0])
+    a, _ = ctx.render(host, cam, 160, 90, 8, 2, seed=3)
+    b, _ = ctx.render(dev, cam, 160, 90, 8, 2, seed=3)
+    assert np.array_equal(a, b)
