@@ -963,15 +963,20 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     return MIPT_OK;
 }
 
-int mipt_tonemap_device(mipt_ctx* c, int kind, const float* in, float* out, size_t width, size_t height) {
-    if (!c || !in || !out || width == 0 || height == 0 || (kind != 0 && kind != 1)) return MIPT_ERR_ARGUMENT;
-    std::lock_guard<std::mutex> lock(c->mutex);   // the Reinhard scratch buffer and the stream belong to the context
+// caller holds the context's lock
+static int tonemap_on_device(mipt_ctx* c, int kind, const float* in, float* out, size_t width, size_t height) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (kind == 1) launch_tonemap_filmic(c->stream, in, out, width * height * 3);
     else launch_tonemap_reinhard(c->stream, in, out, width, height, c->tm_scratch, reinhard_scratch_floats());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     return MIPT_OK;
+}
+
+int mipt_tonemap_device(mipt_ctx* c, int kind, const float* in, float* out, size_t width, size_t height) {
+    if (!c || !in || !out || width == 0 || height == 0 || (kind != 0 && kind != 1)) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);   // the Reinhard scratch buffer and the stream belong to the context
+    return tonemap_on_device(c, kind, in, out, width, height);
 }
 
 int mipt_tonemap(mipt_ctx* c, int kind, const float* in, float* out, size_t width, size_t height) {
@@ -982,7 +987,7 @@ int mipt_tonemap(mipt_ctx* c, int kind, const float* in, float* out, size_t widt
     int rc = ensure_floats(c, &c->stage, &c->stage_cap, n);
     if (rc != MIPT_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->stage, in, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    rc = mipt_tonemap_device(c, kind, c->stage, c->stage, width, height);
+    rc = tonemap_on_device(c, kind, c->stage, c->stage, width, height);
     if (rc != MIPT_OK) return rc;
     HIP_TRY(c, hipMemcpy(out, c->stage, n * sizeof(float), hipMemcpyDeviceToHost));
     return MIPT_OK;
