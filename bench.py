@@ -211,7 +211,8 @@ def main():
                     cols = line.strip().rsplit(",", 3)
                     traffic = (float(cols[2]) + float(cols[3])) * 1024.0 / max(1.0, float(cols[1]))
                     traffic_source = "profiles/r01_pmc_hbm_demo1080p_1024spp.csv (raw FETCH_SIZE + WRITE_SIZE, KB, per launch)"
-        out["roofline"] = {"kernel": "k_sdf_march", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS,
+        out["roofline"] = {"kernel": "k_sdf_march", "bound": "mfma", "bound_detail": "compute side of the roofline: fp32 vector issue, with noise()'s octave transforms on the f32 matrix core",
+                           "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS,
                            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                            "avg_launch_ms": avg_ms, "launches": n_launch,
                            "note": "fp32 vector peak; the octave transforms of noise() run on the f32 matrix core, whose peak is the same 157.3; "

@@ -27,6 +27,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     roof = out["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof, key
+    assert roof["bound"] in ("hbm", "mfma")
     assert roof["kernel"] == "k_sdf_march" and roof["peak"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     cpu = out["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
