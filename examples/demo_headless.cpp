@@ -1,7 +1,7 @@
 // The demo's default scene and camera, rendered headlessly through the C++ scene / render API:
 // a crater ball lit by a large emissive slab, viewed through a 10-degree lens from 30 units away.
 //
-//   demo_headless [width height spp bounces seed out.img]
+//   demo_headless [width height spp bounces seed out.img [passes]]
 //
 // Writes the frame with Image::save (u64 width, u64 height, row-major f32 rgb) and prints timing.
 // Renderer::render runs on the GPU; nothing here has a CPU fallback.
@@ -16,6 +16,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
+#include <vector>
 #include <string>
 
 int main(int argc, char** argv) {
@@ -25,6 +27,9 @@ int main(int argc, char** argv) {
     const std::size_t bounces = argc > 4 ? std::strtoul(argv[4], nullptr, 10) : 8;
     const unsigned long long seed = argc > 5 ? std::strtoull(argv[5], nullptr, 10) : 1;
     const std::string out = argc > 6 ? argv[6] : "demo_headless.img";
+    // more than one pass: the demo's progressive loop with the accumulator on the GPU (ProgressiveFrame); writes the
+    // mean image to `out` and the displayed bytes to `out`.rgba
+    const std::size_t passes = argc > 7 ? std::strtoul(argv[7], nullptr, 10) : 1;
 
     // The demo draws its noise transform at random per process; fix it here.
     const Affine noise = Affine::Translation(Vec(0.417022f, 0.720324f, 0.000114f)) * Linear::RotationX(0.302333f) *
@@ -67,6 +72,22 @@ int main(int argc, char** argv) {
     auto renderer = Renderer{};
     renderer.startThreadPool();
     renderer.setSeed(seed);
+    if (passes > 1) {
+        ProgressiveFrame acc(width, height);
+        std::vector<std::uint8_t> rgba(width * height * 4);
+        const auto p0 = std::chrono::steady_clock::now();
+        for (std::size_t i = 0; i < passes; ++i) {
+            acc.add(renderer, scene, camera, settings);
+            acc.present(rgba.data());   // what the window would show after this pass
+        }
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - p0).count();
+        acc.image().save(out);
+        std::ofstream f(out + ".rgba", std::ios::out | std::ios::binary);
+        f.write(reinterpret_cast<const char*>(rgba.data()), static_cast<std::streamsize>(rgba.size()));
+        std::printf("%zu passes of %zu spp at %zux%zu in %.3f s (%.1f ms per pass incl. display bytes), wrote %s and %s.rgba\n", passes, spp, width, height, s,
+                    1e3 * s / static_cast<double>(passes), out.c_str(), out.c_str());
+        return 0;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     const Image frame = renderer.render(scene, camera, settings);
     const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -170,6 +170,13 @@ int  mipt_render_accumulate(mipt_ctx*, const mipt_scene*, const mipt_camera*, co
 /* device_out[i] = device_in[i] * k  (the `acc * sppInv` of src/Renderer.cpp:102-105); in-place allowed. */
 int  mipt_scale_device(mipt_ctx*, const float* device_in, float k, size_t n_floats, float* device_out);
 
+/* Device buffers of floats for hosts without a HIP toolchain of their own (the C++ host library builds with plain
+ * g++): the accumulator of a progressive display loop.  No counterpart in the reference, whose accumulator is a host
+ * Image (PathTracerDemo.cpp:934-968).  alloc returns n zero-filled floats; read copies p[i] * k to host memory. */
+int  mipt_device_floats_alloc(mipt_ctx*, size_t n, float** out);
+int  mipt_device_floats_zero(mipt_ctx*, float* p, size_t n);
+int  mipt_device_floats_read(mipt_ctx*, const float* p, float k, size_t n, float* host_out);
+void mipt_device_floats_free(mipt_ctx*, float* p);
 /* The display step of the demo's progressive loop (PathTracerDemo.cpp:963-971: `acc += rendered`,
  * scaleImage(acc, 1 / count), tone map, copyToSFImage :524-545) for an accumulator that stays on the
  * device: out = pack(tonemap(device_sum * scale)), 4 bytes per pixel R, G, B, 255 with copyToSFImage's

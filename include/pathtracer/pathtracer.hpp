@@ -693,7 +693,41 @@ public:
     void setSeed(std::uint64_t seed) noexcept;
 
 private:
+    friend class ProgressiveFrame;
     std::unique_ptr<mipt_host::RendererState> m_state;
+};
+
+// The demo's progressive display (PathTracerDemo.cpp:934-974: `acc += rendered; ++count; scaled = scaleImage(acc,
+// 1 / count); copyToSFImage(scaled, img)`) with the accumulator kept on the GPU: per pass nothing comes back to the host
+// but the 4 bytes per pixel that go on screen.  Not part of the reference's API; a program that keeps the reference's
+// loop works unchanged, this is the faster way to write it.
+class ProgressiveFrame {
+public:
+    ProgressiveFrame(std::size_t width, std::size_t height);
+    ~ProgressiveFrame();
+    ProgressiveFrame(const ProgressiveFrame&) = delete;
+    ProgressiveFrame& operator=(const ProgressiveFrame&) = delete;
+
+    std::size_t width() const noexcept { return m_width; }
+    std::size_t height() const noexcept { return m_height; }
+    // passes accumulated since the last reset (the demo's `count`)
+    std::size_t count() const noexcept { return m_count; }
+    // forget what was accumulated (the demo's renderReset)
+    void reset();
+    // One more pass of settings.samplesPerPixel() samples, added on the device.  settings' size must be the frame's.
+    // Returns false when the pass was cancelled (Renderer::cancelRender): the frame then holds the sample batches that
+    // pass had finished, uncounted -- reset() it, as the demo does after every cancel (PathTracerDemo.cpp:976-990).
+    bool add(Renderer&, const Scene&, const Camera&, const RenderSettings&);
+    // mean over everything accumulated, as the demo's `scaled`
+    Image image() const;
+    // copyToSFImage's bytes (PathTracerDemo.cpp:524-545: clamp to [0, 1], times 255, truncated; R, G, B, 255) of the mean,
+    // through no tone mapper (-1, as the demo shows it), Reinhard (0) or filmic (1); rgba holds width * height * 4 bytes
+    void present(std::uint8_t* rgba, int toneMapper = -1) const;
+
+private:
+    std::size_t m_width, m_height, m_count = 0;
+    std::uint64_t m_samples = 0;   // samples per pixel accumulated
+    float* m_device = nullptr;     // width * height * 3 radiance sums on the GPU
 };
 
 // ================================================================================================

@@ -50,7 +50,7 @@ class Stats(C.Structure):
 
 EXPORTS = [
     "mipt_init", "mipt_shutdown", "mipt_cancel", "mipt_last_hip_error", "mipt_set_profiling", "mipt_strerror", "mipt_scene_upload",
-    "mipt_scene_upload_ex",
+    "mipt_scene_upload_ex", "mipt_device_floats_alloc", "mipt_device_floats_zero", "mipt_device_floats_read", "mipt_device_floats_free",
     "mipt_scene_free", "mipt_scene_info", "mipt_render", "mipt_render_accumulate", "mipt_scale_device",
     "mipt_primary_hits", "mipt_trace_rays", "mipt_tonemap", "mipt_tonemap_device", "mipt_affine_inverse",
     "mipt_rotation", "mipt_affine_mul", "mipt_noise_transform", "mipt_world_bounds", "mipt_present_rgba8",
@@ -75,6 +75,11 @@ def dll():
         d.mipt_set_profiling.argtypes = [C.c_void_p, C.c_int]
         d.mipt_scene_upload.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         d.mipt_scene_upload_ex.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.c_uint32, C.POINTER(C.c_void_p)]
+        d.mipt_device_floats_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        d.mipt_device_floats_zero.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        d.mipt_device_floats_read.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_size_t, _f32p]
+        d.mipt_device_floats_free.argtypes = [C.c_void_p, C.c_void_p]
+        d.mipt_device_floats_free.restype = None
         d.mipt_scene_free.argtypes = [C.c_void_p]
         d.mipt_scene_free.restype = None
         d.mipt_scene_info.argtypes = [C.c_void_p, _u32p]

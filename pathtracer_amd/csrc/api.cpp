@@ -845,6 +845,58 @@ int mipt_scale_device(mipt_ctx* c, const float* in, float k, size_t n, float* ou
     return MIPT_OK;
 }
 
+int mipt_device_floats_alloc(mipt_ctx* c, size_t n, float** out) {
+    if (!c || !out || n == 0) return MIPT_ERR_ARGUMENT;
+    *out = nullptr;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    HIP_TRY(c, hipSetDevice(c->device));
+    float* p = nullptr;
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(float));
+    if (e != hipSuccess) {
+        c->last_hip = static_cast<int>(e);
+        return e == hipErrorOutOfMemory ? MIPT_ERR_OUT_OF_MEMORY : MIPT_ERR_HIP;
+    }
+    const hipError_t z = hipMemsetAsync(p, 0, n * sizeof(float), c->stream);
+    const hipError_t y = z == hipSuccess ? hipStreamSynchronize(c->stream) : z;
+    if (y != hipSuccess) {
+        (void)hipFree(p);
+        c->last_hip = static_cast<int>(y);
+        return MIPT_ERR_HIP;
+    }
+    *out = p;
+    return MIPT_OK;
+}
+
+int mipt_device_floats_zero(mipt_ctx* c, float* p, size_t n) {
+    if (!c || !p) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(p, 0, n * sizeof(float), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MIPT_OK;
+}
+
+int mipt_device_floats_read(mipt_ctx* c, const float* p, float k, size_t n, float* host_out) {
+    if (!c || !p || !host_out || n == 0) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int rc = ensure_floats(c, &c->stage, &c->stage_cap, n);
+    if (rc != MIPT_OK) return rc;
+    launch_scale(c->stream, p, k, n, c->stage);
+    HIP_TRY(c, hipMemcpyAsync(host_out, c->stage, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return MIPT_OK;
+}
+
+void mipt_device_floats_free(mipt_ctx* c, float* p) {
+    if (!c || !p) return;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    if (hipSetDevice(c->device) != hipSuccess) return;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(p);
+}
+
 int mipt_present_rgba8(mipt_ctx* c, const float* device_sum, float scale, int tonemap, uint8_t* out_rgba, size_t width, size_t height) {
     if (!c || !device_sum || !out_rgba || width == 0 || height == 0 || tonemap < -1 || tonemap > 1) return MIPT_ERR_ARGUMENT;
     std::lock_guard<std::mutex> lock(c->mutex);

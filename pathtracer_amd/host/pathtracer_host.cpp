@@ -823,24 +823,36 @@ void Renderer::startThreadPool(size_t) {
 }
 void Renderer::stopThreadPool() { m_state->started = false; }
 
-Image Renderer::render(const Scene& scene, const Camera& camera, const RenderSettings& settings) {
-    std::lock_guard<std::mutex> lock(m_state->mutex);
-    mipt_ctx* ctx = mipt_host::shared_context();
-    mipt_scene* dev = mipt_host::sync_scene(scene);
+namespace {
+mipt_camera pack_camera(const Camera& camera) {
     mipt_camera cam{};
     affine_to(camera.transform(), cam.transform);
     cam.aspect = camera.aspectRatio();
     cam.fov_degrees = camera.fieldOfView();
     cam.focal_distance = camera.focalDistance();
     cam.blur_radius = camera.focalBlurRadius();
+    return cam;
+}
+// settings of the renderer's next frame; advances its frame counter (caller holds the renderer's lock)
+mipt_settings next_frame_settings(mipt_host::RendererState& rs, const RenderSettings& settings) {
     mipt_settings st{};
     st.width = static_cast<uint32_t>(settings.width());
     st.height = static_cast<uint32_t>(settings.height());
     st.bounces = static_cast<uint32_t>(settings.numBounces());
     st.spp = static_cast<uint32_t>(settings.samplesPerPixel());
-    st.seed = m_state->seed;
-    st.first_sample = static_cast<uint32_t>(m_state->frame * settings.samplesPerPixel());
-    m_state->frame += 1;
+    st.seed = rs.seed;
+    st.first_sample = static_cast<uint32_t>(rs.frame * settings.samplesPerPixel());
+    rs.frame += 1;
+    return st;
+}
+}   // namespace
+
+Image Renderer::render(const Scene& scene, const Camera& camera, const RenderSettings& settings) {
+    std::lock_guard<std::mutex> lock(m_state->mutex);
+    mipt_ctx* ctx = mipt_host::shared_context();
+    mipt_scene* dev = mipt_host::sync_scene(scene);
+    const mipt_camera cam = pack_camera(camera);
+    const mipt_settings st = next_frame_settings(*m_state, settings);
     Image img(settings.width(), settings.height());
     const int rc = mipt_render(ctx, dev, &cam, &st, img.raw(), nullptr);
     if (rc != MIPT_OK && rc != MIPT_ERR_CANCELLED) mipt_host::fail("mipt_render", rc);
@@ -852,6 +864,52 @@ void Renderer::cancelRender() noexcept { mipt_cancel(mipt_host::shared_context()
 void Renderer::setSeed(std::uint64_t seed) noexcept {
     m_state->seed = seed;
     m_state->frame = 0;
+}
+
+// ================================================================================================
+// progressive display with the accumulator on the GPU (PathTracerDemo.cpp:934-974)
+// ================================================================================================
+ProgressiveFrame::ProgressiveFrame(std::size_t width, std::size_t height) : m_width(width), m_height(height) {
+    const int rc = mipt_device_floats_alloc(mipt_host::shared_context(), width * height * 3, &m_device);
+    if (rc != MIPT_OK) mipt_host::fail("mipt_device_floats_alloc", rc);
+}
+
+ProgressiveFrame::~ProgressiveFrame() { mipt_device_floats_free(mipt_host::shared_context(), m_device); }
+
+void ProgressiveFrame::reset() {
+    const int rc = mipt_device_floats_zero(mipt_host::shared_context(), m_device, m_width * m_height * 3);
+    if (rc != MIPT_OK) mipt_host::fail("mipt_device_floats_zero", rc);
+    m_count = 0;
+    m_samples = 0;
+}
+
+bool ProgressiveFrame::add(Renderer& renderer, const Scene& scene, const Camera& camera, const RenderSettings& settings) {
+    if (settings.width() != m_width || settings.height() != m_height) mipt_host::fail("ProgressiveFrame::add: the settings' size is not the frame's", MIPT_ERR_ARGUMENT);
+    std::lock_guard<std::mutex> lock(renderer.m_state->mutex);
+    mipt_ctx* ctx = mipt_host::shared_context();
+    mipt_scene* dev = mipt_host::sync_scene(scene);
+    const mipt_camera cam = pack_camera(camera);
+    const mipt_settings st = next_frame_settings(*renderer.m_state, settings);
+    const int rc = mipt_render_accumulate(ctx, dev, &cam, &st, m_device, nullptr);
+    if (rc == MIPT_ERR_CANCELLED) return false;
+    if (rc != MIPT_OK) mipt_host::fail("mipt_render_accumulate", rc);
+    m_samples += settings.samplesPerPixel();
+    m_count += 1;
+    return true;
+}
+
+Image ProgressiveFrame::image() const {
+    Image img(m_width, m_height);
+    if (m_samples == 0) return img;
+    const int rc = mipt_device_floats_read(mipt_host::shared_context(), m_device, 1.0f / static_cast<float>(m_samples), m_width * m_height * 3, img.raw());
+    if (rc != MIPT_OK) mipt_host::fail("mipt_device_floats_read", rc);
+    return img;
+}
+
+void ProgressiveFrame::present(std::uint8_t* rgba, int toneMapper) const {
+    const float k = m_samples ? 1.0f / static_cast<float>(m_samples) : 0.0f;
+    const int rc = mipt_present_rgba8(mipt_host::shared_context(), m_device, k, toneMapper, rgba, m_width, m_height);
+    if (rc != MIPT_OK) mipt_host::fail("mipt_present_rgba8", rc);
 }
 
 // ================================================================================================

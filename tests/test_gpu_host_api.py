@@ -90,3 +90,22 @@ def test_unchanged_demo_classes_render_on_the_gpu(ctx):
         want, st = ctx.render(ctx.upload(flat), cam, 32, 32, 4, 2, seed=DEFAULT_SEED)
         assert st["sdf_shades"] > 100
         assert np.array_equal(got, want)
+
+
+def test_progressive_frame_keeps_the_accumulator_on_the_device(ctx, tmp_path):
+    """ProgressiveFrame (the demo's `acc += rendered; ++count; scaled = acc / count; copyToSFImage`, PathTracerDemo.cpp:934-974,
+    with the accumulator on the GPU): three passes of 4 spp are the 12-spp frame bit for bit, and the display bytes are
+    copyToSFImage's of that frame."""
+    exe = os.path.join(LIB, "demo_headless")
+    if not os.path.exists(exe):
+        pytest.skip("demo_headless not built (make -C pathtracer_amd/host example)")
+    out = tmp_path / "frame.img"
+    r = subprocess.run([exe, "96", "64", "4", "8", "7", str(out), "3"], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stderr
+    got = _load_image(out)
+    rgba = np.fromfile(str(out) + ".rgba", np.uint8).reshape(64, 96, 4)
+    alg = api.HostAlgebra()
+    want, _ = ctx.render(ctx.upload(S.demo_scene(alg)), S.demo_camera(alg, 96 / 64), 96, 64, 8, 12, seed=7)
+    assert np.array_equal(got, want) and want.max() > 0
+    assert np.array_equal(rgba[..., :3], (np.clip(want, 0.0, 1.0) * np.float32(255.0)).astype(np.uint8))
+    assert (rgba[..., 3] == 255).all()
