@@ -81,3 +81,23 @@ def test_scene_builders_agree_between_algebras(oracle):
             assert np.array_equal(getattr(a, f), getattr(b, f)), f
     a, b = S.random_scene(alg, 64, seed=5), S.random_scene(oracle, 64, seed=5)
     assert np.array_equal(a.inv, b.inv) and np.array_equal(a.fwd, b.fwd)
+
+
+def test_no_entry_point_takes_the_context_lock_twice():
+    """The context's mutex is not recursive: an entry point that holds it must not call another entry point that takes
+    it (mipt_tonemap once did, and hung).  Checked on the source: every extern "C" body with a lock_guard is free of
+    calls to the other locking entry points."""
+    src = open(os.path.join(os.path.dirname(capi.LIB_PATH), "..", "csrc", "api.cpp")).read()
+    bodies = {}
+    for m in re.finditer(r"^(?:int|void|const char\*)\s+(mipt_\w+)\s*\([^)]*\)\s*\{", src, re.M):
+        depth, i = 1, m.end()
+        while depth:
+            depth += {"{": 1, "}": -1}.get(src[i], 0)
+            i += 1
+        bodies[m.group(1)] = src[m.end():i]
+    assert len(bodies) >= 20
+    locking = {name for name, body in bodies.items() if "lock_guard" in body}
+    assert {"mipt_render", "mipt_tonemap", "mipt_tonemap_device", "mipt_scene_upload_ex"} <= locking
+    for name in locking:
+        called = set(re.findall(r"\b(mipt_\w+)\s*\(", bodies[name])) & locking
+        assert not called, f"{name} holds the context lock and calls {sorted(called)}"
