@@ -148,7 +148,9 @@ int  mipt_scene_upload(mipt_ctx*, const mipt_scene_desc*, mipt_scene** out);
 /* The same with build options.  MIPT_UPLOAD_DEVICE_BVH builds the tree on the GPU (Morton order + radix tree, a few
  * launches) instead of on the host (binned surface-area heuristic): for scenes whose objects move every frame, where
  * the host build (0.5 s at 100,000 objects) would dominate.  Frames are identical; rays cost somewhat more in the
- * GPU-built tree.  MIPT_DEVICE_BVH=1 in the environment makes it the default of mipt_scene_upload. */
+ * GPU-built tree.  MIPT_DEVICE_BVH=1 in the environment makes it the default of mipt_scene_upload.  A scene with fewer
+ * than two analytic primitives has no tree to build and is uploaded as without the flag; unknown flag bits are refused
+ * (MIPT_ERR_ARGUMENT), more than 60 tree levels (only a great many coincident objects get there) with MIPT_ERR_TOO_LARGE. */
 enum { MIPT_UPLOAD_DEVICE_BVH = 1u };
 int  mipt_scene_upload_ex(mipt_ctx*, const mipt_scene_desc*, uint32_t flags, mipt_scene** out);
 void mipt_scene_free(mipt_scene*);

@@ -104,3 +104,13 @@ def test_100k_primitives_device_build_is_fast_and_exact(ctx, alg, oracle):
     a, _ = ctx.render(host, cam, 160, 90, 8, 2, seed=3)
     b, _ = ctx.render(dev, cam, 160, 90, 8, 2, seed=3)
     assert np.array_equal(a, b)
+
+
+def test_unknown_upload_flags_are_refused_and_small_scenes_need_no_tree(ctx, alg):
+    flat = G.sphere_box_scene(alg)
+    with pytest.raises(api.MiptError) as e:
+        api.DeviceScene(ctx, flat, flags=2)
+    assert e.value.status == -1
+    noise = np.load(FIXTURE, allow_pickle=False)["out_noise12"]
+    one = ctx.upload(S.demo_scene(alg, noise), device_bvh=True)   # one analytic primitive beside the crater ball
+    assert one.info()["analytic"] == 1 and one.info()["nodes"] == 1 and one.info()["depth"] == 1
