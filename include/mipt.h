@@ -204,6 +204,16 @@ int  mipt_tonemap(mipt_ctx*, int kind, const float* in_rgb, float* out_rgb, size
 /* The same on device buffers (after the all-reduce of a sharded render); in-place allowed. */
 int  mipt_tonemap_device(mipt_ctx*, int kind, const float* device_in, float* device_out, size_t width, size_t height);
 
+/* No counterpart in the reference: mipt_tonemap_device for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Reinhard's partial sums, which
+ * mipt_tonemap_device keeps in a buffer the context allocated, live in a file-scope device array here (12 KiB on
+ * every GPU the library runs on, held until the process ends); the call allocates and frees nothing, enqueues its
+ * kernels on the context's stream and returns WITHOUT waiting for them.  Results are bit-identical to
+ * mipt_tonemap_device.  width * height above MIPT_NOALLOC_MAX_PIXELS is refused with MIPT_ERR_TOO_LARGE.  All calls
+ * on one GPU share that GPU's array: calls that overlap on one GPU (two contexts or streams) race on it. */
+#define MIPT_NOALLOC_MAX_PIXELS ((size_t)1 << 26)
+int  mipt_tonemap_device_noalloc(mipt_ctx*, int kind, const float* device_in, float* device_out, size_t width, size_t height);
+
 /* ---- host-side helpers (no GPU needed) ------------------------------------------------------ */
 /* Affine::inverse as Object::setTransformation applies it (src/LinearAlgebra.cpp:207-264,
  * src/Object.cpp:15-20), for n transforms.  Returns MIPT_ERR_NOT_INVERTIBLE if any determinant is

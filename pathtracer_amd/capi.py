@@ -54,6 +54,7 @@ EXPORTS = [
     "mipt_scene_free", "mipt_scene_info", "mipt_render", "mipt_render_accumulate", "mipt_scale_device",
     "mipt_primary_hits", "mipt_trace_rays", "mipt_tonemap", "mipt_tonemap_device", "mipt_affine_inverse",
     "mipt_rotation", "mipt_affine_mul", "mipt_noise_transform", "mipt_world_bounds", "mipt_present_rgba8",
+    "mipt_tonemap_device_noalloc",
 ]
 
 _dll = None
@@ -90,6 +91,7 @@ def dll():
         d.mipt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, _f32p, _f32p, C.c_uint32, C.c_uint64, _f32p, _i32p, _f32p]
         d.mipt_tonemap.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, C.c_size_t, C.c_size_t]
         d.mipt_tonemap_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+        d.mipt_tonemap_device_noalloc.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         d.mipt_affine_inverse.argtypes = [C.c_size_t, _f32p, _f32p]
         d.mipt_rotation.argtypes = [C.c_char, C.c_size_t, _f32p, _f32p]
         d.mipt_affine_mul.argtypes = [C.c_size_t, _f32p, _f32p, _f32p]

@@ -40,6 +40,7 @@ struct mipt_ctx {
     float* frame = nullptr;          // per-call radiance sum (mipt_render)
     size_t frame_cap = 0;
     float* tm_scratch = nullptr;     // Reinhard partials
+    float* tm_static = nullptr;      // the same in a file-scope device array (this device's copy), for mipt_tonemap_device_noalloc
     float* stage = nullptr;          // staging for probes / host tone mapping
     size_t stage_cap = 0;
     bool device_bvh = false;        // MIPT_DEVICE_BVH=1: mipt_scene_upload builds the tree on the GPU
@@ -430,6 +431,11 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->tm_scratch), reinhard_scratch_floats() * sizeof(float)) != hipSuccess) {
+        mipt_shutdown(c);
+        return MIPT_ERR_NO_DEVICE;
+    }
+    // this device's copy of the file-scope scratch array (the device is current)
+    if (const hipError_t se = reinhard_static_scratch(&c->tm_static); se != hipSuccess || !c->tm_static) {
         mipt_shutdown(c);
         return MIPT_ERR_NO_DEVICE;
     }
@@ -1029,6 +1035,19 @@ int mipt_tonemap_device(mipt_ctx* c, int kind, const float* in, float* out, size
     if (!c || !in || !out || width == 0 || height == 0 || (kind != 0 && kind != 1)) return MIPT_ERR_ARGUMENT;
     std::lock_guard<std::mutex> lock(c->mutex);   // the Reinhard scratch buffer and the stream belong to the context
     return tonemap_on_device(c, kind, in, out, width, height);
+}
+
+int mipt_tonemap_device_noalloc(mipt_ctx* c, int kind, const float* in, float* out, size_t width, size_t height) {
+    if (!c || !in || !out || width == 0 || height == 0 || (kind != 0 && kind != 1)) return MIPT_ERR_ARGUMENT;
+    if (width > MIPT_NOALLOC_MAX_PIXELS || height > MIPT_NOALLOC_MAX_PIXELS / width) return MIPT_ERR_TOO_LARGE;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    HIP_TRY(c, hipSetDevice(c->device));
+    // Every partial the key kernel reads is written by this call's reduction first, so the array's old
+    // contents (the previous call's) never matter and nothing has to be cleared.
+    if (kind == 1) launch_tonemap_filmic(c->stream, in, out, width * height * 3);
+    else launch_tonemap_reinhard(c->stream, in, out, width, height, c->tm_static, reinhard_scratch_floats());
+    HIP_TRY(c, hipGetLastError());
+    return MIPT_OK;
 }
 
 int mipt_tonemap(mipt_ctx* c, int kind, const float* in, float* out, size_t width, size_t height) {

@@ -75,5 +75,8 @@ void launch_tonemap_filmic(hipStream_t, const float* in, float* out, size_t n_fl
 // Reinhard: scratch holds 3 floats per block of the reduction plus 4 result floats
 void launch_tonemap_reinhard(hipStream_t, const float* in, float* out, size_t width, size_t height, float* scratch, size_t scratch_floats);
 size_t reinhard_scratch_floats();
+// Address, on the CURRENT device, of a file-scope device array of reinhard_scratch_floats() floats (every GPU
+// holds its own copy at its own address): the Reinhard scratch of the entry point that allocates nothing.
+hipError_t reinhard_static_scratch(float** out);
 
 }   // namespace mipt

@@ -1510,6 +1510,18 @@ void launch_tonemap_filmic(hipStream_t st, const float* in, float* out, size_t n
 
 size_t reinhard_scratch_floats() { return 3 * kReinhardBlocks + 4; }
 
+// Reinhard partials for callers that cannot allocate (mipt_tonemap_device_noalloc): a file-scope array in
+// device memory, 12 KiB on every GPU the library runs on, held until the process ends.  In host code the
+// array's name is only a handle for hipGetSymbolAddress; kernels get the address that call returns.
+static __device__ __align__(256) float scratch[3 * kReinhardBlocks + 4];
+
+hipError_t reinhard_static_scratch(float** out) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    *out = e == hipSuccess ? static_cast<float*>(p) : nullptr;
+    return e;
+}
+
 void launch_tonemap_reinhard(hipStream_t st, const float* in, float* out, size_t width, size_t height, float* scratch, size_t) {
     const size_t n_pix = width * height;
     const int blocks = static_cast<int>(grid_for(n_pix, kReinhardBlocks));
