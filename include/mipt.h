@@ -117,6 +117,9 @@ typedef struct {
      * the reference would make them; the queries of pixels that lie outside the screen bounds of every
      * object are answered (miss) without a ray. */
     uint64_t primary_traced;
+    /* Samples per pixel that entered the result: settings->spp, or fewer when mipt_cancel arrived (the sample batches
+     * that had been accumulated by then; a frame that fits one batch reports 0). */
+    uint64_t samples_done;
 } mipt_stats;
 
 enum { MIPT_STAGE_GENERATE = 0, MIPT_STAGE_EXTEND = 1, MIPT_STAGE_SDF_MARCH = 2, MIPT_STAGE_SHADE = 3,
@@ -131,9 +134,18 @@ int  mipt_init(int device, void* stream, mipt_ctx** out);
 void mipt_shutdown(mipt_ctx*);
 /* Renderer::cancelRender (src/Renderer.cpp:174-176): callable from any thread, lock-free.  The
  * running render call drains (the kernels it still has queued return at once, within one bounce)
- * and returns MIPT_ERR_CANCELLED; the sample batch in flight stays out of the result. */
+ * and returns MIPT_ERR_CANCELLED; the sample batch in flight stays out of the result.  What comes back is
+ * the mean over the sample batches accumulated before the cancel (mipt_stats::samples_done of them per pixel;
+ * every pixel at fewer samples, where the reference returns some pixels finished and the rest black); a frame
+ * that was one batch comes back black with samples_done = 0.  mipt_render_accumulate adds those batches'
+ * unnormalised sum, so the caller divides by samples_done. */
 int  mipt_cancel(mipt_ctx*);
 int  mipt_last_hip_error(const mipt_ctx*);
+/* No counterpart in the reference (its working set is the host Image).  A context keeps its working set on the GPU
+ * between calls: the path arena (sized by the largest sample batch rendered so far; by default at most 80 % of the
+ * memory that was free and at most 48 GiB, MIPT_BATCH_PATHS = path slots overrides), the frame and staging buffers.
+ * mipt_trim frees them all (they are allocated again on demand); mipt_shutdown frees them too. */
+int  mipt_trim(mipt_ctx*);
 /* Measurement aid (no counterpart in the reference): when on, render calls bracket every kernel launch
  * with HIP events on the context's stream and report per-stage times in mipt_stats. */
 int  mipt_set_profiling(mipt_ctx*, int on);

@@ -120,6 +120,10 @@ class Context:
     def set_profiling(self, on):
         check(capi.dll().mipt_set_profiling(self.h, 1 if on else 0), "mipt_set_profiling")
 
+    def trim(self):
+        """Frees the working set the context keeps on the GPU between calls."""
+        check(capi.dll().mipt_trim(self.h), "mipt_trim")
+
     def cancel(self):
         check(capi.dll().mipt_cancel(self.h), "mipt_cancel")
 
@@ -135,7 +139,7 @@ class Context:
                     shade_noise_calls=int(st.shade_noise_calls), ms_device=float(st.ms_device),
                     stage_ms=dict(zip(STAGES, (float(x) for x in st.stage_ms))),
                     stage_launches=dict(zip(STAGES, (int(x) for x in st.stage_launches))),
-                    primary_traced=int(st.primary_traced))
+                    primary_traced=int(st.primary_traced), samples_done=int(st.samples_done))
 
     def render(self, scene, cam16, w, h, bounces, spp, seed=1, first_sample=0, flags=0):
         """Renderer::render: (h, w, 3) float32 mean image and the call's statistics."""

@@ -45,7 +45,7 @@ class Stats(C.Structure):
                 ("sdf_far_evals", C.c_uint64), ("sdf_near_evals", C.c_uint64), ("sdf_noise_calls", C.c_uint64),
                 ("shade_evals", C.c_uint64), ("shade_noise_calls", C.c_uint64),
                 ("ms_device", C.c_double), ("stage_ms", C.c_double * 6), ("stage_launches", C.c_uint64 * 6),
-                ("primary_traced", C.c_uint64)]
+                ("primary_traced", C.c_uint64), ("samples_done", C.c_uint64)]
 
 
 EXPORTS = [
@@ -54,7 +54,7 @@ EXPORTS = [
     "mipt_scene_free", "mipt_scene_info", "mipt_render", "mipt_render_accumulate", "mipt_scale_device",
     "mipt_primary_hits", "mipt_trace_rays", "mipt_tonemap", "mipt_tonemap_device", "mipt_affine_inverse",
     "mipt_rotation", "mipt_affine_mul", "mipt_noise_transform", "mipt_world_bounds", "mipt_present_rgba8",
-    "mipt_tonemap_device_noalloc",
+    "mipt_tonemap_device_noalloc", "mipt_trim",
 ]
 
 _dll = None
@@ -74,6 +74,7 @@ def dll():
         d.mipt_cancel.argtypes = [C.c_void_p]
         d.mipt_last_hip_error.argtypes = [C.c_void_p]
         d.mipt_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        d.mipt_trim.argtypes = [C.c_void_p]
         d.mipt_scene_upload.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         d.mipt_scene_upload_ex.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.c_uint32, C.POINTER(C.c_void_p)]
         d.mipt_device_floats_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]

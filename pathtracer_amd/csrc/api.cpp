@@ -37,6 +37,10 @@ struct mipt_ctx {
     size_t slots_cap = 0, bits_cap = 0;
     PathBuffers pb{};
     void* arena = nullptr;
+    uint32_t* vis_tiles = nullptr;   // image tiles that can see anything, for frames whose objects cover part of the screen
+    size_t vis_cap = 0;
+    std::vector<uint32_t> vis_host;
+    hipEvent_t batch_ev[2] = {nullptr, nullptr};   // end of the last two sample batches (at most two are queued at a time)
     float* frame = nullptr;          // per-call radiance sum (mipt_render)
     size_t frame_cap = 0;
     float* tm_scratch = nullptr;     // Reinhard partials
@@ -87,14 +91,24 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-constexpr size_t kBytesPerSlot = 4 * 16 + 8 + 16 + 4 * 4 + 1;   // rays, attenuation, radiance, hit key, hit position, four queues, bitmap (rounded up)
+// Per-slot arrays of the path arena, in the order ensure_slots lays them out: ray origin, ray direction,
+// attenuation, radiance (float4 each), hit key (u64), hit position (float4), two live-path queues, the SDF-march
+// queue and the SDF-shade queue (u32 each).  The memory budget below is priced from the same table.
+constexpr size_t kSlotArrayBytes[10] = {16, 16, 16, 16, 8, 16, 4, 4, 4, 4};
+constexpr size_t slot_bytes() {
+    size_t b = 0;
+    for (size_t v : kSlotArrayBytes) b += v;
+    return b;
+}
 constexpr size_t kMaxSlots = (size_t(1) << 31) - 256;      // slot indices are 32-bit
+constexpr size_t kDefaultArenaCeiling = size_t(48) << 30;  // bytes; MIPT_BATCH_PATHS asks for more
 
-// Paths in flight per sample batch.  Large batches matter: every bounce of every batch ends in a
-// latency-bound tail (the longest SDF marches, a few rays on an otherwise idle chip), and fewer batches
-// mean fewer tails -- the demo frame at 1080p, 1024 spp runs 1.4x faster as one batch of 2.1 G paths
-// (221 GB) than as sixteen.  The default therefore takes up to 80 % of the memory that is free on the
-// device; MIPT_BATCH_PATHS overrides it.
+// Paths in flight per sample batch.  Every bounce of every batch ends in a latency-bound tail (the longest SDF
+// marches, a few rays on an otherwise idle chip), so fewer, larger batches are faster; but the arena stays
+// allocated until mipt_trim or mipt_shutdown and whatever else lives on this GPU (another context, the caller's
+// tensors, RCCL's buffers) needs memory too.  Default: up to 80 % of the memory that is free, at most 48 GiB;
+// MIPT_BATCH_PATHS (path slots) overrides both.  Slots exist only for pixels inside the screen bounds of the scene's
+// objects, so the demo frame at 1080p, 1024 spp (3 % of the pixels) is one batch of 7 GB.
 size_t batch_path_budget(const mipt_ctx* c) {
     if (const char* e = std::getenv("MIPT_BATCH_PATHS")) {
         const long long v = std::atoll(e);
@@ -102,8 +116,9 @@ size_t batch_path_budget(const mipt_ctx* c) {
     }
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return size_t(128) << 20;
-    free_b += c->slots_cap * kBytesPerSlot;   // the arena is replaced when it has to grow
-    const size_t budget = free_b / 10 * 8 / kBytesPerSlot;
+    free_b += c->slots_cap * slot_bytes();   // the arena is replaced when it has to grow
+    const size_t bytes = std::min(free_b / 10 * 8, kDefaultArenaCeiling);
+    const size_t budget = bytes * 8 / (slot_bytes() * 8 + 1);   // one bit of the live-path bitmap per slot
     return std::min(std::max(budget, size_t(1) << 20), kMaxSlots);
 }
 
@@ -126,9 +141,10 @@ int ensure_slots(mipt_ctx* c, size_t slots, size_t words) {
         off += align_up(bytes, 256);
         return o;
     };
-    const size_t o_ro = take(n * 16), o_rd = take(n * 16), o_att = take(n * 16), o_rad = take(n * 16);
-    const size_t o_key = take(n * 8), o_pos = take(n * 16);
-    const size_t o_q0 = take(n * 4), o_q1 = take(n * 4), o_qs = take(n * 4), o_qss = take(n * 4);
+    size_t o_arr[10];
+    for (int k = 0; k < 10; ++k) o_arr[k] = take(n * kSlotArrayBytes[k]);
+    const size_t o_ro = o_arr[0], o_rd = o_arr[1], o_att = o_arr[2], o_rad = o_arr[3], o_key = o_arr[4], o_pos = o_arr[5];
+    const size_t o_q0 = o_arr[6], o_q1 = o_arr[7], o_qs = o_arr[8], o_qss = o_arr[9];
     const size_t o_cnt = take(sizeof(BounceCounters) * (kMaxBounces + 1));
     const size_t o_tot = take(sizeof(Totals));
     const size_t o_bits = take(words * 8);
@@ -310,17 +326,66 @@ void enqueue_bounces(mipt_ctx* c, const mipt_scene* sc, const BatchParams& bp, u
     launch_finish_batch(c->stream, c->pb, bounces, primaries);
 }
 
-int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const mipt_settings* st, float* d_sum, mipt_stats* stats) {
+// Image tiles (8 x 8 pixels) that touch one of the cull rectangles, in row-major order; empty = all of them.
+void visible_tiles(const CullRects& cull, uint32_t tiles_x, uint32_t tiles_y, std::vector<uint32_t>& out) {
+    out.clear();
+    std::vector<uint8_t> mark(static_cast<size_t>(tiles_x) * tiles_y, 0);
+    size_t n = 0;
+    for (int k = 0; k < cull.n; ++k) {
+        const int tx0 = std::max(cull.r[k][0], 0) / 8, ty0 = std::max(cull.r[k][1], 0) / 8;
+        const int tx1 = std::min(cull.r[k][2] / 8, static_cast<int>(tiles_x) - 1), ty1 = std::min(cull.r[k][3] / 8, static_cast<int>(tiles_y) - 1);
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) {
+                uint8_t& m = mark[static_cast<size_t>(ty) * tiles_x + tx];
+                n += m ? 0 : 1;
+                m = 1;
+            }
+    }
+    if (n == mark.size()) return;   // the whole frame: no table needed
+    out.reserve(std::max<size_t>(n, 1));
+    for (size_t t = 0; t < mark.size(); ++t)
+        if (mark[t]) out.push_back(static_cast<uint32_t>(t));
+    if (out.empty()) out.push_back(0u);   // nothing on screen: one tile keeps every launch well-formed (its pixels trace nothing)
+}
+
+// `samples_done` (nullable) receives the samples per pixel that entered d_sum: st->spp, or fewer after a cancel.
+int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const mipt_settings* st, float* d_sum, mipt_stats* stats,
+                uint32_t* samples_done = nullptr) {
+    if (samples_done) *samples_done = 0;
     if (!c || !sc || !cam || !st || !d_sum) return MIPT_ERR_ARGUMENT;
     if (st->width < 2 || st->height < 2 || st->spp == 0 || st->bounces == 0) return MIPT_ERR_ARGUMENT;
     if (st->bounces > static_cast<uint32_t>(kMaxBounces)) return MIPT_ERR_TOO_LARGE;
     // pixel ids cover whole 8 x 8 tiles (BatchParams::tiles_x)
     const uint32_t tiles_x = (st->width + 7u) / 8u, tiles_y = (st->height + 7u) / 8u;
-    const size_t n_pix = static_cast<size_t>(tiles_x) * tiles_y * 64;
-    if (n_pix > (size_t(1) << 31)) return MIPT_ERR_TOO_LARGE;
+    if (static_cast<size_t>(tiles_x) * tiles_y * 64 > (size_t(1) << 31)) return MIPT_ERR_TOO_LARGE;
     HIP_TRY(c, hipSetDevice(c->device));
     c->cancel.store(0);
     if (c->cancel_host) *c->cancel_host = 0u;
+    const CameraRec cr = pack_camera(*cam);
+    const CullRects cull = screen_rects(sc, *cam, st->width, st->height);
+    // path slots only for the tiles that can see anything
+    visible_tiles(cull, tiles_x, tiles_y, c->vis_host);
+    const bool listed = !c->vis_host.empty();
+    const size_t n_pix = (listed ? c->vis_host.size() : static_cast<size_t>(tiles_x) * tiles_y) * 64;
+    if (listed) {
+        if (c->vis_host.size() > c->vis_cap) {
+            if (c->vis_tiles) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                HIP_TRY(c, hipFree(c->vis_tiles));
+                c->vis_tiles = nullptr;
+                c->vis_cap = 0;
+            }
+            const size_t cap = std::max<size_t>(c->vis_host.size(), 4096);
+            const hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->vis_tiles), cap * sizeof(uint32_t));
+            if (e != hipSuccess) {
+                c->last_hip = static_cast<int>(e);
+                return e == hipErrorOutOfMemory ? MIPT_ERR_OUT_OF_MEMORY : MIPT_ERR_HIP;
+            }
+            c->vis_cap = cap;
+        }
+        // (a copy from pageable memory returns once the source has been staged; the table is reused by the next frame only after that)
+        HIP_TRY(c, hipMemcpyAsync(c->vis_tiles, c->vis_host.data(), c->vis_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    }
     // equal batches, as few as the memory budget allows; on an allocation failure try smaller ones
     size_t per_batch_max = std::max<size_t>(1, batch_path_budget(c) / n_pix);
     uint32_t per_batch = 0;
@@ -334,15 +399,16 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         (void)hipGetLastError();
         per_batch_max = std::max<size_t>(1, per_batch / 2);
     }
-    const CameraRec cr = pack_camera(*cam);
-    const CullRects cull = screen_rects(sc, *cam, st->width, st->height);
     HIP_TRY(c, hipMemsetAsync(c->pb.totals, 0, sizeof(Totals), c->stream));
     c->ev_used = 0;
     c->spans.clear();
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    uint32_t done = 0;
+    uint32_t done = 0, batch_no = 0;
     int status = MIPT_OK;
     while (done < st->spp) {
+        // at most two batches are queued at a time: the stream never runs dry between batches, and a cancel
+        // arrives at most two batches late (every kernel of a cancelled frame returns at once anyway)
+        if (batch_no >= 2) HIP_TRY(c, hipEventSynchronize(c->batch_ev[batch_no & 1]));
         if (c->cancel.load(std::memory_order_relaxed)) {
             status = MIPT_ERR_CANCELLED;
             break;
@@ -354,8 +420,9 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.width = st->width;
         bp.height = st->height;
         bp.tiles_x = tiles_x;
+        bp.vis_tiles = listed ? c->vis_tiles : nullptr;
         bp.first_sample = st->first_sample + done;
-        bp.flags = st->flags | (c->full_march ? kFlagFullMarch : 0u);
+        bp.flags = (st->flags & static_cast<uint32_t>(MIPT_FLAG_NO_JITTER)) | (c->full_march ? kFlagFullMarch : 0u);
         bp.lane_threshold = c->lane_threshold;
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
@@ -364,17 +431,18 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         enqueue_bounces(c, sc, bp, st->bounces, 1);
         launch_latch_cancel(c->stream, c->pb);
         { StageTimer t(c, MIPT_STAGE_ACCUMULATE); launch_accumulate(c->stream, bp, c->pb, d_sum); }
+        HIP_TRY(c, hipEventRecord(c->batch_ev[batch_no & 1], c->stream));
         done += now;
-        // keep at most a couple of batches queued so that cancellation stays responsive
-        if (done < st->spp) HIP_TRY(c, hipStreamSynchronize(c->stream));
+        ++batch_no;
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     if (c->cancel.load(std::memory_order_relaxed)) status = MIPT_ERR_CANCELLED;   // possibly in the middle of the last batch
+    Totals t{};
+    HIP_TRY(c, hipMemcpy(&t, c->pb.totals, sizeof(t), hipMemcpyDeviceToHost));
+    if (samples_done) *samples_done = static_cast<uint32_t>(t.samples_done);
     if (stats) {
-        Totals t{};
-        HIP_TRY(c, hipMemcpy(&t, c->pb.totals, sizeof(t), hipMemcpyDeviceToHost));
         float ms = 0.0f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
         stats->paths = static_cast<uint64_t>(st->width) * st->height * done;
@@ -387,6 +455,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         stats->shade_evals = t.shade_near_evals;
         stats->shade_noise_calls = t.shade_noise_calls;
         stats->primary_traced = t.primary_traced;
+        stats->samples_done = t.samples_done;
         stats->ms_device = ms;
         for (int k = 0; k < 6; ++k) {
             stats->stage_ms[k] = 0.0;
@@ -430,6 +499,8 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
         c->own_stream = true;
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->batch_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->batch_ev[1], hipEventDisableTiming) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->tm_scratch), reinhard_scratch_floats() * sizeof(float)) != hipSuccess) {
         mipt_shutdown(c);
         return MIPT_ERR_NO_DEVICE;
@@ -466,6 +537,9 @@ void mipt_shutdown(mipt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->arena) (void)hipFree(c->arena);
+    if (c->vis_tiles) (void)hipFree(c->vis_tiles);
+    for (hipEvent_t e : c->batch_ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->frame) (void)hipFree(c->frame);
     if (c->stage) (void)hipFree(c->stage);
     if (c->tm_scratch) (void)hipFree(c->tm_scratch);
@@ -485,6 +559,20 @@ int mipt_cancel(mipt_ctx* c) {
 }
 
 int mipt_last_hip_error(const mipt_ctx* c) { return c ? c->last_hip : 0; }
+
+int mipt_trim(mipt_ctx* c) {
+    if (!c) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (void** p : {&c->arena, reinterpret_cast<void**>(&c->frame), reinterpret_cast<void**>(&c->stage), reinterpret_cast<void**>(&c->vis_tiles)})
+        if (*p) {
+            HIP_TRY(c, hipFree(*p));
+            *p = nullptr;
+        }
+    c->slots_cap = c->bits_cap = c->frame_cap = c->stage_cap = c->vis_cap = 0;
+    return MIPT_OK;
+}
 
 int mipt_set_profiling(mipt_ctx* c, int on) {
     if (!c) return MIPT_ERR_ARGUMENT;
@@ -834,9 +922,11 @@ int mipt_render(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
     int rc = ensure_floats(c, &c->frame, &c->frame_cap, n);
     if (rc != MIPT_OK) return rc;
     HIP_TRY(c, hipMemsetAsync(c->frame, 0, n * sizeof(float), c->stream));   // Image starts black (src/Image.cpp:8-13)
-    rc = render_into(c, sc, cam, st, c->frame, stats);
+    uint32_t entered = 0;
+    rc = render_into(c, sc, cam, st, c->frame, stats, &entered);
     if (rc != MIPT_OK && rc != MIPT_ERR_CANCELLED) return rc;
-    launch_scale(c->stream, c->frame, 1.0f / static_cast<float>(st->spp), n, c->frame);   // acc * sppInv
+    // acc * sppInv over the samples that entered the frame: all of them, or the batches finished before a cancel
+    launch_scale(c->stream, c->frame, 1.0f / static_cast<float>(std::max(entered, 1u)), n, c->frame);
     HIP_TRY(c, hipMemcpyAsync(out_rgb, c->frame, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return rc;

@@ -170,7 +170,12 @@ BvhResult build_bvh(std::vector<BuildBox> boxes, int max_depth) {
         Aabb box, none;
         box.reset();
         box.grow(boxes[0].lo, boxes[0].hi);
-        none.reset();   // inverted: never hit
+        // The absent second child: a box at +infinity on every axis.  Both plane distances of an axis are then
+        // infinite with the sign of the ray's direction there, so the slab test's entry distance is +inf (beyond any
+        // limit) or its exit distance is -inf (before the entry): no ray ever enters it.  (An inverted finite box
+        // would not do: the test orders the two plane distances itself, and every ray would pass.)
+        const float inf = std::numeric_limits<float>::infinity();
+        for (int a = 0; a < 3; ++a) none.lo[a] = none.hi[a] = inf;
         Builder::set_child(bl.nodes[0], 0, box, ~static_cast<int32_t>(boxes[0].prim));
         Builder::set_child(bl.nodes[0], 1, none, ~static_cast<int32_t>(boxes[0].prim));
         bl.depth_seen = 1;

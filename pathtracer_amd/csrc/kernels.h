@@ -40,6 +40,11 @@ struct BatchParams {
     // pixel id = tile * 64 + (y & 7) * 8 + (x & 7): a wave's 64 paths are a square patch of the image (their
     // rays meet the same few objects) and still occupy 8 full cache lines of every per-slot array.
     uint32_t tiles_x;
+    // With tiles: which image tile each group of 64 pixel ids stands for (tile index ty * tiles_x + tx), or null for
+    // all tiles in order.  A frame whose objects cover a small part of the screen enumerates only the tiles that
+    // touch their screen bounds, so path slots (and the memory behind them) exist only for pixels that can see
+    // anything; n_pix is then 64 times the number of listed tiles.
+    const uint32_t* vis_tiles;
     uint32_t first_sample;  // global sample index of sample 0 of this batch
     uint32_t flags;
     uint32_t lane_threshold;   // SDF near field: waiting lanes from which a wave evaluates one point per lane

@@ -330,10 +330,15 @@ __device__ __forceinline__ bool pixel_of(const BatchParams& bp, uint32_t id, uin
         x = id - y * bp.width;
         return id < bp.n_pix;
     }
-    const uint32_t tile = id >> 6, ty = tile / bp.tiles_x, tx = tile - ty * bp.tiles_x;
+    if (id >= bp.n_pix) {
+        x = y = 0u;
+        return false;
+    }
+    const uint32_t tile = bp.vis_tiles ? bp.vis_tiles[id >> 6] : id >> 6;
+    const uint32_t ty = tile / bp.tiles_x, tx = tile - ty * bp.tiles_x;
     x = tx * 8u + (id & 7u);
     y = ty * 8u + ((id >> 3) & 7u);
-    return id < bp.n_pix && x < bp.width && y < bp.height;
+    return x < bp.width && y < bp.height;
 }
 
 // =============================================================================================
@@ -1267,6 +1272,7 @@ __global__ void __launch_bounds__(256) k_accumulate(BatchParams bp, PathBuffers 
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t samples = bp.n_slots / bp.n_pix;
     const uint32_t words_per_sample = (bp.n_pix + 63u) / 64u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) pb.totals->samples_done += samples;   // launches on one stream: no two of them overlap
     for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < bp.n_pix; id += stride) {
         uint32_t x, y;
         if (!pixel_of(bp, id, x, y)) continue;
