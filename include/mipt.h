@@ -120,6 +120,11 @@ typedef struct {
     /* Samples per pixel that entered the result: settings->spp, or fewer when mipt_cancel arrived (the sample batches
      * that had been accumulated by then; a frame that fits one batch reports 0). */
     uint64_t samples_done;
+    /* Filled only while mipt_set_counting(ctx, 1) is in force: BVH nodes visited and primitives tested (Object::hitRay
+     * calls) by the closest-hit queries of the call; the reference tests every object for every ray
+     * (src/ObjectTree.cpp:22-63), rays * objects. */
+    uint64_t node_visits;
+    uint64_t prim_tests;
 } mipt_stats;
 
 enum { MIPT_STAGE_GENERATE = 0, MIPT_STAGE_EXTEND = 1, MIPT_STAGE_SDF_MARCH = 2, MIPT_STAGE_SHADE = 3,
@@ -149,6 +154,10 @@ int  mipt_trim(mipt_ctx*);
 /* Measurement aid (no counterpart in the reference): when on, render calls bracket every kernel launch
  * with HIP events on the context's stream and report per-stage times in mipt_stats. */
 int  mipt_set_profiling(mipt_ctx*, int on);
+/* Measurement aid (no counterpart in the reference): when on, render calls run the counting build of the closest-hit
+ * kernels -- the same traversal in the same order, plus two counters per lane -- and report mipt_stats::node_visits
+ * and prim_tests.  Frames are unchanged; the counting build is a few per cent slower. */
+int  mipt_set_counting(mipt_ctx*, int on);
 const char* mipt_strerror(int status);
 
 /* ---- scene -------------------------------------------------------------------------------- */
@@ -208,6 +217,12 @@ int  mipt_primary_hits(mipt_ctx*, const mipt_scene*, const mipt_camera*, uint32_
  * path (pixel = i, sample = 0).  out_first_prim / out_first_t (nullable) report the first hit. */
 int  mipt_trace_rays(mipt_ctx*, const mipt_scene*, uint32_t n, const float* ray_pos3, const float* ray_dir3,
                      uint32_t bounces, uint64_t seed, float* out_rgb, int32_t* out_first_prim, float* out_first_t);
+
+/* The signed distance of SDF primitive `prim` (kinds MIPT_CRATERBALL and up) at n points of the object's LOCAL frame,
+ * evaluated by the device code the march uses: CraterBallObject::signedDistance (PathTracerDemo.cpp:361-466),
+ * FractalObject::signedDistance (src/Object.cpp:198-252), RoughBoxObject (:237-246), RoughSphereObject (:165-182),
+ * WeirdWallObject (:281-328).  pos3 = n x 3 floats, out = n floats (host). */
+int  mipt_sdf_eval(mipt_ctx*, const mipt_scene*, uint32_t prim, uint32_t n, const float* pos3, float* out);
 
 /* ---- tone mapping ------------------------------------------------------------------------- */
 /* ReinhardToneMapper / FilmicToneMapper::operator() (src/ToneMapper.cpp:6-72): kind 0 Reinhard,

@@ -72,6 +72,26 @@ def fast_lib():
     return _fast
 
 
+_v3 = None
+
+
+def v3_lib():
+    """liboracle_v3.so (the restatement compiled for x86-64-v3, same results as liboracle.so: the timed CPU baseline),
+    or None where it is missing or this host's cores lack AVX2."""
+    global _v3
+    if _v3 is None:
+        try:
+            flags = open("/proc/cpuinfo").read()
+        except OSError:
+            flags = ""
+        if " avx2" in flags and " bmi2" in flags and " fma" in flags:
+            _v3 = _load(os.path.join(_HERE, "liboracle_v3.so"))
+            if _v3 is not None:
+                _v3.orc_scene_create.restype = C.c_void_p
+                _v3.orc_counter_uniform01.restype = C.c_float
+    return _v3
+
+
 def ref():
     """The compiled reference, or None where it was not built."""
     global _ref
@@ -136,10 +156,10 @@ class _Api:
 class Oracle(_Api):
     """liboracle.so; with fast_math=True the -ffast-math build (for timing only)."""
 
-    def __init__(self, fast_math=False):
-        dll = fast_lib() if fast_math else lib()
+    def __init__(self, fast_math=False, tuned=False):
+        dll = fast_lib() if fast_math else (v3_lib() if tuned else lib())
         if dll is None:
-            raise RuntimeError("oracle/liboracle_fast.so missing: run `make -C oracle`")
+            raise RuntimeError("oracle/liboracle_fast.so or liboracle_v3.so missing (or no AVX2 here): run `make -C oracle`")
         super().__init__(dll, "orc_")
 
     def scene(self, s):

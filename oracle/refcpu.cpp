@@ -984,6 +984,29 @@ struct orc_scene {
     SceneData d;
 };
 
+// Rays that do not share a random-number sequence are independent: large scenes (every ray scans every
+// object) spread them over the host's cores.  Results do not depend on the split.
+template <class F>
+static void for_each_ray(uint32_t n, uint64_t work_per_ray, F&& body) {
+    unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (static_cast<uint64_t>(n) * work_per_ray < (1u << 22) || n < 2 * threads) threads = 1;
+    if (threads == 1) {
+        for (uint32_t i = 0; i < n; ++i) body(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    std::atomic<uint32_t> next{0};
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([&] {
+            for (;;) {
+                const uint32_t i0 = next.fetch_add(16);
+                if (i0 >= n) return;
+                for (uint32_t i = i0; i < std::min(n, i0 + 16); ++i) body(i);
+            }
+        });
+    for (auto& th : pool) th.join();
+}
+
 extern "C" {
 
 void orc_rotation_x(float a, float out[9]) { std::memcpy(out, rotation_x(a).m, sizeof(float) * 9); }
@@ -1125,7 +1148,7 @@ void orc_camera_rays(const float cam16[16], uint32_t n, const float* sx, const f
 
 void orc_closest_hit(const orc_scene* s, uint32_t n, const float* pos, const float* dir, int32_t* out_prim,
                      float* out_t, float* out_pos) {
-    for (uint32_t i = 0; i < n; ++i) {
+    for_each_ray(n, s->d.prims.size(), [&](uint32_t i) {
         const Ray r{v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), v3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2])};
         const Hit h = closest_hit(s->d, r, nullptr);
         out_prim[i] = h.prim;
@@ -1135,7 +1158,7 @@ void orc_closest_hit(const orc_scene* s, uint32_t n, const float* pos, const flo
             out_pos[3 * i + 1] = h.pos.y;
             out_pos[3 * i + 2] = h.pos.z;
         }
-    }
+    });
 }
 
 void orc_deflect(const float mat14[14], uint32_t n, const float* inbound, const float* normal, uint32_t rng_mode,
@@ -1164,16 +1187,21 @@ void orc_deflect(const float mat14[14], uint32_t n, const float* inbound, const 
 
 void orc_trace(const orc_scene* s, uint32_t n, const float* pos, const float* dir, uint32_t depth, uint32_t rng_mode,
                uint64_t seed, float* out_rgb) {
-    MinstdRng seq(seed);
+    if (rng_mode == ORC_RNG_COUNTER) {   // every ray has its own random stream
+        for_each_ray(n, s->d.prims.size(), [&](uint32_t i) {
+            const Ray r{v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), v3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2])};
+            CounterRng rng(seed, i, 0);
+            const V3 c = trace(s->d, r, depth, rng, nullptr);
+            out_rgb[3 * i] = c.x;
+            out_rgb[3 * i + 1] = c.y;
+            out_rgb[3 * i + 2] = c.z;
+        });
+        return;
+    }
+    MinstdRng seq(seed);   // one sequence drawn ray after ray, as the reference's single worker draws it
     for (uint32_t i = 0; i < n; ++i) {
         const Ray r{v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), v3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2])};
-        V3 c;
-        if (rng_mode == ORC_RNG_COUNTER) {
-            CounterRng rng(seed, i, 0);
-            c = trace(s->d, r, depth, rng, nullptr);
-        } else {
-            c = trace(s->d, r, depth, seq, nullptr);
-        }
+        const V3 c = trace(s->d, r, depth, seq, nullptr);
         out_rgb[3 * i] = c.x;
         out_rgb[3 * i + 1] = c.y;
         out_rgb[3 * i + 2] = c.z;
@@ -1184,16 +1212,16 @@ void orc_primary_hits(const orc_scene* s, const float cam16[16], uint32_t W, uin
                       float* out_t) {
     const Cam c = load_cam(cam16);
     const float max_w = static_cast<float>(W - 1), max_h = static_cast<float>(H - 1);
-    for (uint32_t y = 0; y < H; ++y) {
+    // (an SDF primitive costs far more than its share of the object count: price every ray highly enough to use the cores)
+    for_each_ray(W * H, s->d.prims.size() + 4096, [&](uint32_t i) {
+        const uint32_t y = i / W, x = i - y * W;
         const float py = static_cast<float>(y) / max_h;
-        for (uint32_t x = 0; x < W; ++x) {
-            const float px = static_cast<float>(x) / max_w;
-            const Ray r = view_ray_with_lens(c, px, py, 0.0f, 0.0f);
-            const Hit h = closest_hit(s->d, r, nullptr);
-            out_prim[y * W + x] = h.prim;
-            out_t[y * W + x] = h.prim >= 0 ? h.t : 0.0f;
-        }
-    }
+        const float px = static_cast<float>(x) / max_w;
+        const Ray r = view_ray_with_lens(c, px, py, 0.0f, 0.0f);
+        const Hit h = closest_hit(s->d, r, nullptr);
+        out_prim[i] = h.prim;
+        out_t[i] = h.prim >= 0 ? h.t : 0.0f;
+    });
 }
 
 int orc_render(const orc_scene* s, const float cam16[16], uint32_t W, uint32_t H, uint32_t bounces, uint32_t spp,

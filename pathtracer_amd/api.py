@@ -120,6 +120,10 @@ class Context:
     def set_profiling(self, on):
         check(capi.dll().mipt_set_profiling(self.h, 1 if on else 0), "mipt_set_profiling")
 
+    def set_counting(self, on):
+        """Counting build of the closest-hit kernels: stats gain node_visits and prim_tests."""
+        check(capi.dll().mipt_set_counting(self.h, 1 if on else 0), "mipt_set_counting")
+
     def trim(self):
         """Frees the working set the context keeps on the GPU between calls."""
         check(capi.dll().mipt_trim(self.h), "mipt_trim")
@@ -139,7 +143,8 @@ class Context:
                     shade_noise_calls=int(st.shade_noise_calls), ms_device=float(st.ms_device),
                     stage_ms=dict(zip(STAGES, (float(x) for x in st.stage_ms))),
                     stage_launches=dict(zip(STAGES, (int(x) for x in st.stage_launches))),
-                    primary_traced=int(st.primary_traced), samples_done=int(st.samples_done))
+                    primary_traced=int(st.primary_traced), samples_done=int(st.samples_done),
+                    node_visits=int(st.node_visits), prim_tests=int(st.prim_tests))
 
     def render(self, scene, cam16, w, h, bounces, spp, seed=1, first_sample=0, flags=0):
         """Renderer::render: (h, w, 3) float32 mean image and the call's statistics."""
@@ -181,6 +186,13 @@ class Context:
                                          prim.ctypes.data_as(capi._i32p) if first_hit else None,
                                          fp(t) if first_hit else None), "mipt_trace_rays")
         return (out, prim, t) if first_hit else out
+
+    def sdf_eval(self, scene, prim, pos):
+        """Signed distance of SDF primitive `prim` at (n, 3) points of its local frame."""
+        pos = f32(pos)
+        out = np.zeros(pos.shape[0], np.float32)
+        check(capi.dll().mipt_sdf_eval(self.h, scene.h, int(prim), pos.shape[0], fp(pos), fp(out)), "mipt_sdf_eval")
+        return out
 
     def tonemap(self, kind, img):
         img = f32(img)

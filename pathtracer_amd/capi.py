@@ -45,7 +45,8 @@ class Stats(C.Structure):
                 ("sdf_far_evals", C.c_uint64), ("sdf_near_evals", C.c_uint64), ("sdf_noise_calls", C.c_uint64),
                 ("shade_evals", C.c_uint64), ("shade_noise_calls", C.c_uint64),
                 ("ms_device", C.c_double), ("stage_ms", C.c_double * 6), ("stage_launches", C.c_uint64 * 6),
-                ("primary_traced", C.c_uint64), ("samples_done", C.c_uint64)]
+                ("primary_traced", C.c_uint64), ("samples_done", C.c_uint64),
+                ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64)]
 
 
 EXPORTS = [
@@ -54,7 +55,7 @@ EXPORTS = [
     "mipt_scene_free", "mipt_scene_info", "mipt_render", "mipt_render_accumulate", "mipt_scale_device",
     "mipt_primary_hits", "mipt_trace_rays", "mipt_tonemap", "mipt_tonemap_device", "mipt_affine_inverse",
     "mipt_rotation", "mipt_affine_mul", "mipt_noise_transform", "mipt_world_bounds", "mipt_present_rgba8",
-    "mipt_tonemap_device_noalloc", "mipt_trim",
+    "mipt_tonemap_device_noalloc", "mipt_trim", "mipt_sdf_eval", "mipt_set_counting",
 ]
 
 _dll = None
@@ -75,6 +76,7 @@ def dll():
         d.mipt_last_hip_error.argtypes = [C.c_void_p]
         d.mipt_set_profiling.argtypes = [C.c_void_p, C.c_int]
         d.mipt_trim.argtypes = [C.c_void_p]
+        d.mipt_set_counting.argtypes = [C.c_void_p, C.c_int]
         d.mipt_scene_upload.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         d.mipt_scene_upload_ex.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.c_uint32, C.POINTER(C.c_void_p)]
         d.mipt_device_floats_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
@@ -90,6 +92,7 @@ def dll():
         d.mipt_scale_device.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_size_t, C.c_void_p]
         d.mipt_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, _i32p, _f32p]
         d.mipt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, _f32p, _f32p, C.c_uint32, C.c_uint64, _f32p, _i32p, _f32p]
+        d.mipt_sdf_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _f32p, _f32p]
         d.mipt_tonemap.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, C.c_size_t, C.c_size_t]
         d.mipt_tonemap_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         d.mipt_tonemap_device_noalloc.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]

@@ -53,6 +53,7 @@ struct mipt_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // optional per-launch timing
+    bool counting = false;          // mipt_set_counting: the traversal kernels count node visits and primitive tests
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
     struct Span { int stage; size_t e0, e1; };
@@ -73,6 +74,7 @@ struct mipt_scene {
     void* d_crater_masks = nullptr;
     uint32_t n_nodes = 0, n_analytic = 0, n_sdf = 0;
     int depth = 0;
+    std::vector<uint8_t> kinds;   // per primitive, for argument checks
     // padded world boxes that together hold everything a ray can hit: the analytic primitives' common
     // box and the SDF primitives' boxes (merged into one if there are many)
     std::vector<std::array<float, 6>> cull_boxes;
@@ -316,7 +318,7 @@ void enqueue_bounces(mipt_ctx* c, const mipt_scene* sc, const BatchParams& bp, u
     for (uint32_t b = 0; b < bounces; ++b) {
         const int done = b == 0 ? first_done : 0;
         if (b > 0) launch_latch_cancel(c->stream, c->pb);
-        if (done < 1) { StageTimer t(c, MIPT_STAGE_EXTEND); launch_extend(c->stream, sc->dev, bp, c->pb, b, sc->depth); }
+        if (done < 1) { StageTimer t(c, MIPT_STAGE_EXTEND); launch_extend(c->stream, sc->dev, bp, c->pb, b, sc->depth, c->counting); }
         if (sc->n_sdf && done < 2) { StageTimer t(c, MIPT_STAGE_SDF_MARCH); launch_sdf_march(c->stream, sc->dev, bp, c->pb, b); }
         { StageTimer t(c, MIPT_STAGE_SHADE); launch_shade(c->stream, sc->dev, bp, c->pb, b, bounces); }
         if (sc->n_sdf) { StageTimer t(c, MIPT_STAGE_SHADE_SDF); launch_shade_sdf(c->stream, sc->dev, bp, c->pb, b, bounces); }
@@ -427,7 +429,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
         launch_latch_cancel(c->stream, c->pb);
-        { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate_extend(c->stream, cr, sc->dev, bp, c->pb, cull, sc->depth); }
+        { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate_extend(c->stream, cr, sc->dev, bp, c->pb, cull, sc->depth, c->counting); }
         enqueue_bounces(c, sc, bp, st->bounces, 1);
         launch_latch_cancel(c->stream, c->pb);
         { StageTimer t(c, MIPT_STAGE_ACCUMULATE); launch_accumulate(c->stream, bp, c->pb, d_sum); }
@@ -456,6 +458,8 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         stats->shade_noise_calls = t.shade_noise_calls;
         stats->primary_traced = t.primary_traced;
         stats->samples_done = t.samples_done;
+        stats->node_visits = t.node_visits;
+        stats->prim_tests = t.prim_tests;
         stats->ms_device = ms;
         for (int k = 0; k < 6; ++k) {
             stats->stage_ms[k] = 0.0;
@@ -578,6 +582,13 @@ int mipt_set_profiling(mipt_ctx* c, int on) {
     if (!c) return MIPT_ERR_ARGUMENT;
     std::lock_guard<std::mutex> lock(c->mutex);
     c->profiling = on != 0;
+    return MIPT_OK;
+}
+
+int mipt_set_counting(mipt_ctx* c, int on) {
+    if (!c) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    c->counting = on != 0;
     return MIPT_OK;
 }
 
@@ -881,6 +892,7 @@ int mipt_scene_upload_ex(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags, 
             s->cull_boxes.push_back(m);
         }
     }
+    s->kinds.assign(d->kind, d->kind + n);
     s->n_nodes = n_nodes;
     s->n_analytic = n_analytic;
     s->n_sdf = static_cast<uint32_t>(sdf.size());
@@ -1108,6 +1120,22 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
             else std::memcpy(&out_first_t[i], &fb, 4);
         }
     }
+    return MIPT_OK;
+}
+
+int mipt_sdf_eval(mipt_ctx* c, const mipt_scene* sc, uint32_t prim, uint32_t n, const float* pos3, float* out) {
+    if (!c || !sc || !pos3 || !out || n == 0) return MIPT_ERR_ARGUMENT;
+    if (n > (1u << 28)) return MIPT_ERR_TOO_LARGE;
+    if (prim >= sc->dev.n_prims || sc->kinds[prim] < MIPT_CRATERBALL) return MIPT_ERR_ARGUMENT;   // not an SDF primitive
+    std::lock_guard<std::mutex> lock(c->mutex);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int rc = ensure_floats(c, &c->stage, &c->stage_cap, static_cast<size_t>(n) * 4);
+    if (rc != MIPT_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->stage, pos3, static_cast<size_t>(n) * 12, hipMemcpyHostToDevice, c->stream));
+    launch_sdf_eval(c->stream, sc->dev, prim, c->lane_threshold, c->stage, n, c->stage + static_cast<size_t>(n) * 3);
+    HIP_TRY(c, hipMemcpyAsync(out, c->stage + static_cast<size_t>(n) * 3, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
     return MIPT_OK;
 }
 

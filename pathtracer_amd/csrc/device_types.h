@@ -88,6 +88,7 @@ struct Totals {
     unsigned long long sdf_far_evals, sdf_near_evals, sdf_noise_calls;   // sdf_march: SDF evaluations by kind, noise() calls
     unsigned long long shade_near_evals, shade_noise_calls;              // shade_sdf: the same for the normals
     unsigned long long primary_traced;                                   // primary rays that were traced rather than culled on screen
+    unsigned long long node_visits, prim_tests;                          // counting build of the traversal only
     unsigned long long samples_done;                                     // samples per pixel that entered the frame (batches accumulated before a cancel)
 };
 

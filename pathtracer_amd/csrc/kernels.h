@@ -61,11 +61,15 @@ struct CullRects {
 };
 
 // generate + first extend fused; needs counters zeroed; fills queue[0] and the SDF queue of bounce 0
-void launch_generate_extend(hipStream_t, const CameraRec&, const SceneDev&, const BatchParams&, const PathBuffers&, const CullRects&, int bvh_depth);
-void launch_extend(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, int bvh_depth);
+// `count`: the counting build of the traversal (same steps, same order; adds node visits and primitive tests to Totals)
+void launch_generate_extend(hipStream_t, const CameraRec&, const SceneDev&, const BatchParams&, const PathBuffers&, const CullRects&, int bvh_depth,
+                            bool count = false);
+void launch_extend(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, int bvh_depth, bool count = false);
 // big-crater candidates of a crater ball: 12 floats per cell of the n^3 lattice cube at `base` (x-major)
 void launch_crater_cells(hipStream_t, const float off[3], const int base[3], int n, float* out);
 void launch_sdf_march(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce);
+// signed distance of SDF primitive `prim` at n points of its local frame (device arrays)
+void launch_sdf_eval(hipStream_t, const SceneDev&, uint32_t prim, uint32_t lane_threshold, const float* pos3, uint32_t n, float* out);
 void launch_shade(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, uint32_t max_bounces);
 void launch_shade_sdf(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, uint32_t max_bounces);
 void launch_finish_batch(hipStream_t, const PathBuffers&, uint32_t bounces, uint32_t n_slots);

@@ -500,13 +500,25 @@ __device__ __forceinline__ void trav_leaf_step(const SceneDev& sc, Trav& t, cons
 // Steps the wave's rays until fewer than `keep_busy` lanes hold an unfinished ray (so the caller can
 // refill) -- or, with keep_busy = 0, until all are finished.  Always takes at least one step.  All 64
 // lanes call.
-__device__ __forceinline__ void trav_run(const SceneDev& sc, Trav& t, int* stack, uint32_t keep_busy) {
+// COUNT: the counting build -- the same steps in the same order, and per lane the number of nodes visited and of
+// primitives tested (what the traversal's memory traffic is priced by).
+struct TravCounts {
+    uint32_t nodes, prims;
+};
+template <bool COUNT>
+__device__ __forceinline__ void trav_run(const SceneDev& sc, Trav& t, int* stack, uint32_t keep_busy, TravCounts& counts) {
     constexpr uint32_t kLeafQuorum = 20;   // lanes with a pending leaf that make a leaf step worth its cost
     for (;;) {
-        if (trav_wants_inner(t)) trav_inner_step(sc, t, stack);
+        if (trav_wants_inner(t)) {
+            trav_inner_step(sc, t, stack);
+            if (COUNT) ++counts.nodes;
+        }
         const uint32_t n_leaf = static_cast<uint32_t>(__popcll(__ballot(trav_wants_leaf(t))));
         if (n_leaf >= kLeafQuorum || (n_leaf > 0 && !__ballot(trav_wants_inner(t)))) {
-            if (trav_wants_leaf(t)) trav_leaf_step(sc, t, stack);
+            if (trav_wants_leaf(t)) {
+                trav_leaf_step(sc, t, stack);
+                if (COUNT) ++counts.prims;
+            }
         }
         const uint32_t n_unfinished = static_cast<uint32_t>(__popcll(__ballot(t.busy && !trav_finished(t))));
         if (n_unfinished == 0 || n_unfinished < keep_busy) return;
@@ -656,7 +668,7 @@ __device__ __forceinline__ bool xcd_cursor_take(XcdCursor& q, bool want, uint32_
 // reach an SDF box are written to HBM (ray, hit) and queued for the stages that follow; on the demo
 // scene that is ~10 % of the paths, the rest cost no memory traffic at all.
 // =============================================================================================
-template <int STACK, int CAP>
+template <int STACK, int CAP, bool COUNT>
 __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev sc, BatchParams bp, PathBuffers pb, CullRects cull) {
     if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
     __shared__ int s_stack[STACK * 256];
@@ -696,6 +708,7 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
     uint32_t s_cur = blockIdx.y - gridDim.y;             // wave-uniform (wraps; advanced before use)
     Trav t;
     t.busy = false;
+    TravCounts counts{0u, 0u};
     for (;;) {
         // refill: idle lanes start their next sample
         if (!t.busy && s_next < samples) {
@@ -709,7 +722,7 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
         // The wave's 64 rays of one sample run to the end together: neighbouring pixels take about equally
         // long, and their queue entries then name 64 consecutive slots, which is what lets the kernels that
         // read the queue later fetch the paths' state in full cache lines.
-        trav_run(sc, t, stack, 0u);
+        trav_run<COUNT>(sc, t, stack, 0u, counts);
         // finished rays: keep what hit something or reaches an SDF box
         const bool fin = trav_finished(t);
         bool keep = false, wants_sdf = false;
@@ -739,13 +752,17 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
     pending_flush(to_sdf, &pb.counters[0].n_sdf, pb.sdf_queue);
     wave_add_total(&pb.totals->sdf_rays, n_sdf_rays);
     wave_add_total(&pb.totals->primary_traced, visible ? (samples - blockIdx.y + gridDim.y - 1u) / gridDim.y : 0u);
+    if (COUNT) {
+        wave_add_total(&pb.totals->node_visits, counts.nodes);
+        wave_add_total(&pb.totals->prim_tests, counts.prims);
+    }
 }
 
 // =============================================================================================
 // extend: closest hit for the rays of the live-path queue (bounces after the first, or rays loaded
 // from the host).  Persistent waves; a lane that finishes its ray takes the next one from the queue.
 // =============================================================================================
-template <int STACK>
+template <int STACK, bool COUNT>
 __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
     if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
     __shared__ int s_stack[STACK * 256];
@@ -770,6 +787,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
     XcdCursor cursor{0u, 0u, blockIdx.x & 7u, 0u};
     Trav t;
     t.busy = false;
+    TravCounts counts{0u, 0u};
     for (;;) {
         // refill idle lanes from the queue
         uint32_t i = 0;
@@ -782,7 +800,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
             continue;
         }
         const uint32_t n_busy = static_cast<uint32_t>(__popcll(__ballot(t.busy)));
-        trav_run(sc, t, stack, xcd_cursor_empty(cursor) ? 0u : (3u * n_busy) / 4u);
+        trav_run<COUNT>(sc, t, stack, xcd_cursor_empty(cursor) ? 0u : (3u * n_busy) / 4u, counts);
         const bool fin = trav_finished(t);
         bool wants_sdf = false;
         if (fin) {
@@ -796,6 +814,10 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
     }
     pending_flush(to_sdf, &pb.counters[bounce].n_sdf, pb.sdf_queue);
     wave_add_total(&pb.totals->sdf_rays, n_sdf_rays);
+    if (COUNT) {
+        wave_add_total(&pb.totals->node_visits, counts.nodes);
+        wave_add_total(&pb.totals->prim_tests, counts.prims);
+    }
 }
 
 #include "craterball.h"
@@ -1035,6 +1057,44 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
     wave_add_total(&pb.totals->sdf_far_evals, c_far);
     wave_add_total(&pb.totals->sdf_near_evals, c_near);
     wave_add_total(&pb.totals->sdf_noise_calls, c_noise);
+}
+
+// =============================================================================================
+// Parity probe: the signed distance of SDF primitive `prim` at n points of its local frame, through the very
+// evaluators the march uses (a wave of 64 points asks together, so the per-lane evaluator serves full waves and
+// the cooperative one the last, short wave -- or every wave, as the lane threshold says).
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_sdf_eval(SceneDev sc, uint32_t prim, uint32_t lane_threshold, const float* pos3, uint32_t n, float* out) {
+    __shared__ __attribute__((aligned(16))) float s_coop[4 * kNearLdsFloats];
+    const uint32_t lane = __lane_id();
+    float* lds = s_coop + (threadIdx.x >> 6) * kNearLdsFloats;
+    const CoopLane cl = make_coop_lane(sc.noise_oct, lane);
+    CraterTableRegs crater_regs = no_crater_table();
+    const PrimRec* pr = sc.prims + prim;
+    const uint32_t kind = pr->kind;
+    const f3 prm = mk3(pr->p[0], pr->p[1], pr->p[2]);
+    const uint32_t crater_base = __float_as_uint(pr->p[3]), crater_count = __float_as_uint(pr->p[4]);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (n + stride - 1) / stride;   // every lane of a wave runs every round: wave_near is wave-wide
+    uint32_t c_near = 0, c_noise = 0;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = i < n;
+        const f3 p = valid ? mk3(pos3[3 * i], pos3[3 * i + 1], pos3[3 * i + 2]) : mk3(1.0f, 0.0f, 0.0f);
+        float v = 0.0f, s = 0.0f;
+        bool wants = false;
+        if (kind == 3u) {
+            s = norm(p) - 0.5f;
+            v = s;
+            wants = valid && !(static_cast<double>(s) > 0.1);   // the far field returns the sphere distance itself
+        } else if (kind == 4u) {
+            v = fractal_sdf(p);
+        } else if (valid) {
+            v = plain_sdf(kind, prm, sc.noise_raw, p);
+        }
+        if (kind == 3u) wave_near(sc.craters, sc.crater_masks, crater_regs, cl, lds, lane, lane_threshold, wants, p, prm, s, crater_base, crater_count, v, c_near, c_noise);
+        if (valid) out[i] = v;
+    }
 }
 
 // =============================================================================================
@@ -1444,25 +1504,37 @@ static inline uint32_t grid_for(size_t n, uint32_t cap = 256u * 32u) {
 }
 
 void launch_generate_extend(hipStream_t st, const CameraRec& cam, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, const CullRects& cull,
-                            int bvh_depth) {
+                            int bvh_depth, bool count) {
     // one thread per pixel; enough sample stripes to fill the chip when the image is small
     const uint32_t bx = (bp.n_pix + 255u) / 256u, samples = bp.n_slots / bp.n_pix;
     const uint32_t by = std::max(1u, std::min(samples, (4096u + bx - 1u) / bx));
     const dim3 grid(bx, by), block(256);
     // (traversal stack, pending-queue capacity): LDS per block = STACK KiB + 8 CAP bytes, at most 64 KiB
-    if (bvh_depth <= 8) hipLaunchKernelGGL((k_generate_extend<8, 1024>), grid, block, 0, st, cam, sc, bp, pb, cull);
-    else if (bvh_depth <= 24) hipLaunchKernelGGL((k_generate_extend<24, 512>), grid, block, 0, st, cam, sc, bp, pb, cull);
-    else if (bvh_depth <= 40) hipLaunchKernelGGL((k_generate_extend<40, 256>), grid, block, 0, st, cam, sc, bp, pb, cull);
-    else hipLaunchKernelGGL((k_generate_extend<60, 128>), grid, block, 0, st, cam, sc, bp, pb, cull);
+#define MIPT_LAUNCH_GE(STACK, CAP)                                                                                        \
+    do {                                                                                                                 \
+        if (count) hipLaunchKernelGGL((k_generate_extend<STACK, CAP, true>), grid, block, 0, st, cam, sc, bp, pb, cull);  \
+        else hipLaunchKernelGGL((k_generate_extend<STACK, CAP, false>), grid, block, 0, st, cam, sc, bp, pb, cull);       \
+    } while (0)
+    if (bvh_depth <= 8) MIPT_LAUNCH_GE(8, 1024);
+    else if (bvh_depth <= 24) MIPT_LAUNCH_GE(24, 512);
+    else if (bvh_depth <= 40) MIPT_LAUNCH_GE(40, 256);
+    else MIPT_LAUNCH_GE(60, 128);
+#undef MIPT_LAUNCH_GE
 }
 
-void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, int bvh_depth) {
+void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, int bvh_depth, bool count) {
     // persistent waves: every wave drains the queue
     const dim3 grid(256u * 4u), block(256);
-    if (bvh_depth <= 8) hipLaunchKernelGGL(k_extend<8>, grid, block, 0, st, sc, bp, pb, bounce);
-    else if (bvh_depth <= 24) hipLaunchKernelGGL(k_extend<24>, grid, block, 0, st, sc, bp, pb, bounce);
-    else if (bvh_depth <= 40) hipLaunchKernelGGL(k_extend<40>, grid, block, 0, st, sc, bp, pb, bounce);
-    else hipLaunchKernelGGL(k_extend<60>, grid, block, 0, st, sc, bp, pb, bounce);
+#define MIPT_LAUNCH_EX(STACK)                                                                          \
+    do {                                                                                              \
+        if (count) hipLaunchKernelGGL((k_extend<STACK, true>), grid, block, 0, st, sc, bp, pb, bounce); \
+        else hipLaunchKernelGGL((k_extend<STACK, false>), grid, block, 0, st, sc, bp, pb, bounce);      \
+    } while (0)
+    if (bvh_depth <= 8) MIPT_LAUNCH_EX(8);
+    else if (bvh_depth <= 24) MIPT_LAUNCH_EX(24);
+    else if (bvh_depth <= 40) MIPT_LAUNCH_EX(40);
+    else MIPT_LAUNCH_EX(60);
+#undef MIPT_LAUNCH_EX
 }
 
 void launch_crater_cells(hipStream_t st, const float off[3], const int base[3], int n, float* out) {
@@ -1473,6 +1545,10 @@ void launch_sdf_march(hipStream_t st, const SceneDev& sc, const BatchParams& bp,
     // persistent waves: enough blocks to fill the chip a few times over, every wave drains the queue
     if (sc.plain_sdf) hipLaunchKernelGGL(k_sdf_march<true>, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce);
     else hipLaunchKernelGGL(k_sdf_march<false>, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce);
+}
+
+void launch_sdf_eval(hipStream_t st, const SceneDev& sc, uint32_t prim, uint32_t lane_threshold, const float* pos3, uint32_t n, float* out) {
+    hipLaunchKernelGGL(k_sdf_eval, dim3(grid_for(n, 256u * 4u)), dim3(256), 0, st, sc, prim, lane_threshold, pos3, n, out);
 }
 
 void launch_shade(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, uint32_t max_bounces) {

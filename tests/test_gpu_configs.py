@@ -1,0 +1,172 @@
+"""Configurations 4 and 5 at their own sizes, and the crater ball's distance function probed directly.
+
+  * config 5 -- 20,000 mirrors / glass / emitters, 3840 x 2160, 16 bounces: paths of random rays followed through all
+    16 bounces against the CPU restatement's scan over every object (first hits bit for bit, radiance path by path with
+    shared random numbers), then one full-size frame checked through properties that need no CPU render of that size;
+  * config 4 -- 1,000,000 spheres / boxes, 3840 x 2160, 8 bounces: the same, on fewer rays (a CPU scan of a million
+    objects per cast) and at a low sample count (the configuration's 4,096 spp are 34 G paths; linearity in the samples
+    is what lets eight GPUs split them);
+  * CraterBallObject::signedDistance (PathTracerDemo.cpp:361-466) on the device against the restatement at 200,000
+    near-field points, with the error printed and bounded, for both wave evaluators;
+  * the demo scene's primary-hit map at 256 x 256 with the measured disagreement printed and bounded at twice what was
+    measured when the bound was set.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases as G
+from pathtracer_amd import api, scene as S
+
+pytestmark = pytest.mark.gpu
+
+FIXTURE = os.path.join(os.path.dirname(__file__), "golden", "reference_cases.npz")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context()
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def alg():
+    return api.HostAlgebra()
+
+
+def _unit(v):
+    return (v / np.linalg.norm(v, axis=-1, keepdims=True)).astype(np.float32)
+
+
+def _rays_into_scene(n, seed, extent=12.0, inner=8.0):
+    r = np.random.RandomState(seed)
+    o = r.uniform(-extent, extent, (n, 3)).astype(np.float32)
+    return o, _unit(r.uniform(-inner, inner, (n, 3)) - o)
+
+
+def _frame_properties(ctx, ds, cam, W, H, bounces, spp, small_spp, rays_per_path_min):
+    """Sample linearity, bitwise reproducibility, accounting, resolution independence of a full-size frame."""
+    full, st = ctx.render(ds, cam, W, H, bounces, spp, seed=3)
+    assert full.shape == (H, W, 3) and np.isfinite(full).all()
+    assert st["paths"] == W * H * spp and st["samples_done"] == spp
+    assert st["rays"] > rays_per_path_min * st["paths"]
+    again, st2 = ctx.render(ds, cam, W, H, bounces, spp, seed=3)
+    assert np.array_equal(full, again) and st["rays"] == st2["rays"]
+    a, _ = ctx.render(ds, cam, W, H, bounces, spp // 2, seed=3, first_sample=0)
+    b, _ = ctx.render(ds, cam, W, H, bounces, spp // 2, seed=3, first_sample=spp // 2)
+    assert np.allclose(full, 0.5 * (a + b), rtol=2e-5, atol=1e-6)
+    small, _ = ctx.render(ds, cam, W // 4, H // 4, bounces, small_spp, seed=11)
+    assert full.mean() > 0 and abs(full.mean() - small.mean()) <= 0.03 * small.mean(), (full.mean(), small.mean())
+    return full, st
+
+
+def test_config5_20k_mixed_4k_16_bounces(ctx, alg, oracle):
+    flat = S.random_scene(alg, 20_000, seed=9, radius_scale=2.0, glass_mirror_mix=True)
+    ds = ctx.upload(flat)
+    osc = oracle.scene(flat)
+    # Scene::trace (src/Scene.cpp:18-78) for 4,096 rays at 16 bounces: reflection, refraction, inside hits, emitters
+    o, d = _rays_into_scene(4096, 31)
+    want = osc.trace(o, d, 16, rng_mode=1, seed=5)
+    got, prim, t = ctx.trace_rays(ds, o, d, 16, seed=5, first_hit=True)
+    wp, wt, _ = osc.closest_hit(o, d)
+    assert np.array_equal(wp, prim) and np.array_equal(wt[wp >= 0], t[wp >= 0])
+    close = np.all(np.abs(want - got) <= 1e-4 * np.maximum(1.0, np.abs(want)), axis=1)
+    assert close.mean() >= 0.995, close.mean()
+    assert (wp >= 0).mean() > 0.5 and (want.max(axis=1) > 0).mean() > 0.1
+    # the frame at the configuration's size
+    W, H = 3840, 2160
+    cam = S.random_scene_camera(alg, W / H)
+    _, st = _frame_properties(ctx, ds, cam, W, H, 16, 32, 512, rays_per_path_min=2.0)
+    print(f"config 5 frame: {st['rays'] / st['paths']:.3f} rays per path, {st['ms_device']:.1f} ms at 32 spp")
+
+
+def test_config4_1m_primitives_4k_8_bounces(ctx, alg, oracle):
+    flat = S.random_scene(alg, 1_000_000, seed=7, radius_scale=0.46)
+    ds = ctx.upload(flat)
+    info = ds.info()
+    assert info["analytic"] == 1_000_000 and info["nodes"] == 999_999
+    osc = oracle.scene(flat)
+    o, d = _rays_into_scene(768, 41)
+    want = osc.trace(o, d, 8, rng_mode=1, seed=6)
+    got, prim, t = ctx.trace_rays(ds, o, d, 8, seed=6, first_hit=True)
+    wp, wt, _ = osc.closest_hit(o, d)
+    assert np.array_equal(wp, prim) and np.array_equal(wt[wp >= 0], t[wp >= 0])
+    close = np.all(np.abs(want - got) <= 1e-4 * np.maximum(1.0, np.abs(want)), axis=1)
+    assert close.mean() >= 0.995, close.mean()
+    assert (wp >= 0).mean() > 0.3
+    W, H = 3840, 2160
+    cam = S.random_scene_camera(alg, W / H)
+    _, st = _frame_properties(ctx, ds, cam, W, H, 8, 16, 256, rays_per_path_min=1.5)
+    print(f"config 4 frame: {st['rays'] / st['paths']:.3f} rays per path, {st['ms_device']:.1f} ms at 16 spp")
+    ctx.trim()
+
+
+# What was measured on an MI355X when these bounds were set (the test prints the current figures):
+# |device - restatement| over 195,904 near-field points: max 5.5e-6, 99.9th percentile 1.03e-6, mean 2.1e-7 (the SDF's
+# values span +-0.3; the march's stop threshold is 1e-4).  The bounds are twice what was measured.
+SDF_MAX_ERR = 1.1e-5
+SDF_P999_ERR = 2.1e-6
+
+
+def test_craterball_sdf_values_against_the_restatement(alg, oracle):
+    z = np.load(FIXTURE, allow_pickle=False)
+    noise = z["out_noise12"]
+    flat = S.demo_scene(alg, noise)
+    r = np.random.RandomState(77)
+    n = 200_000
+    # near field: |p| - 0.5 <= 0.1 runs the crater / noise body; a few far points check the early-out
+    radius = np.concatenate([r.uniform(0.36, 0.6, n - 4096), r.uniform(0.6, 1.2, 4096)])
+    p = (_unit(r.normal(size=(n, 3))) * radius[:, None]).astype(np.float32)
+    want = oracle.sdf_craterball(flat.params[0, :3], noise, p)
+    values = {}
+    for thr in ("1", "65", None):   # every point by the per-lane evaluator, by the cooperative one, and the default mix
+        if thr is None:
+            os.environ.pop("MIPT_LANE_THRESHOLD", None)
+        else:
+            os.environ["MIPT_LANE_THRESHOLD"] = thr
+        try:
+            c = api.Context()
+        finally:
+            os.environ.pop("MIPT_LANE_THRESHOLD", None)
+        try:
+            values[thr] = c.sdf_eval(c.upload(flat), 0, p)
+        finally:
+            c.close()
+    assert np.array_equal(values["1"], values["65"]) and np.array_equal(values["1"], values[None]), "the two evaluators disagree"
+    got = values[None]
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    near = np.linalg.norm(p, axis=1) - 0.5 <= 0.1
+    print(f"crater-ball SDF, {near.sum()} near-field points: max |err| = {err[near].max():.3e}, 99.9th percentile = "
+          f"{np.percentile(err[near], 99.9):.3e}, mean = {err[near].mean():.3e}; far field max |err| = {err[~near].max():.3e}")
+    assert err[~near].max() == 0.0                     # |p| - 0.5, exact
+    assert err[near].max() <= SDF_MAX_ERR and np.percentile(err[near], 99.9) <= SDF_P999_ERR
+    assert np.abs(want[near]).max() < 0.35 and want[near].std() > 0.02
+
+
+# Measured when the bounds were set, 65,536 pixels per view.  Demo camera: 0 pixels disagree on hit / miss, 534 common
+# hits, max |dt| 5.5e-5.  Close-up: 1 pixel disagrees, 31,335 common hits, 99.9th percentile of |dt| 9.9e-5 (the march stops
+# within 1e-4 of the surface, so two marches whose SDF values differ in the last bits may stop one step apart), max |dt|
+# 2.4e-3 on one ray that grazes a crater rim and meets the surface at its next crossing.  Bounds: twice the measured figures.
+DEMO_MISMATCH_PIXELS = 2
+DEMO_DT_P999 = 2e-4
+DEMO_DT_MAX = 5e-3
+
+
+@pytest.mark.parametrize("close", [False, True])
+def test_primary_hits_demo_scene_256(close, ctx, alg, oracle):
+    z = np.load(FIXTURE, allow_pickle=False)
+    flat = S.demo_scene(alg, z["out_noise12"])
+    cam = G.demo_closeup_camera(alg) if close else S.demo_camera(alg)
+    w = h = 256
+    want_prim, want_t = oracle.scene(flat).primary_hits(cam, w, h)
+    got_prim, got_t = ctx.primary_hits(ctx.upload(flat), cam, w, h)
+    mismatch = int((want_prim != got_prim).sum())
+    both = (want_prim >= 0) & (got_prim >= 0)
+    dt = np.abs(want_t - got_t)[both]
+    print(f"demo scene ({'close-up' if close else 'demo camera'}), 256 x 256: {mismatch} pixels disagree on hit / miss, "
+          f"{both.sum()} common hits, max |dt| = {dt.max():.3e}, 99.9th percentile = {np.percentile(dt, 99.9):.3e}")
+    assert mismatch <= DEMO_MISMATCH_PIXELS, mismatch
+    assert both.sum() > (30_000 if close else 400)
+    assert np.percentile(dt, 99.9) <= DEMO_DT_P999 and dt.max() <= DEMO_DT_MAX

@@ -4,8 +4,9 @@ Bars, per stage:
   * analytic primitives (sphere, box, triangle): primary-hit primitive indices identical, hit distances
     bit-identical (the exact part of the device code evaluates the reference's expressions in the
     reference's order, without fused multiply-add);
-  * crater-ball SDF: the device evaluates the SDF with FMA contraction and hardware exp2/log2/rcp/rsq,
-    so marches may stop one step apart: at most 0.5 % of pixels may disagree on hit / miss, distances
+  * crater-ball SDF: the device evaluates the SDF with FMA contraction and hardware exp2/log2/rcp/rsq
+    (values within 5.5e-6 of the reference's, tests/test_gpu_configs.py), so marches may stop one step apart:
+    at most one pixel of a primary-hit map may disagree on hit / miss (none was measured), distances
     agree to 2e-4 (the march's own stop tolerance is 1e-4);
   * traced paths / rendered images with the shared counter-based random numbers: identical ray counts
     on analytic scenes, radiance equal to 1e-4 relative on at least 99.5 % of paths (a path whose
@@ -102,11 +103,14 @@ def test_primary_hits_demo_scene(close, ctx, alg, oracle, golden):
     got_prim, got_t = ctx.primary_hits(ctx.upload(flat), cam, w, h)
     want_prim = golden["demo_close_prim" if close else "demo_primary_prim"]
     want_t = golden["demo_close_t" if close else "demo_primary_t"]
-    mismatch = (want_prim != got_prim).mean()
-    assert mismatch <= 0.005, f"{mismatch:.4f} of pixels disagree on hit / miss"
+    mismatch = int((want_prim != got_prim).sum())
     both = (want_prim >= 0) & (got_prim >= 0)
+    dt = np.abs(want_t - got_t)[both]
+    print(f"reference fixture, {'close-up' if close else 'demo camera'}: {mismatch} of {w * h} pixels disagree on hit / miss, max |dt| = {dt.max():.3e}")
+    # measured: no pixel disagrees at either size (tests/test_gpu_configs.py holds the 256 x 256 maps and their figures)
+    assert mismatch <= 1, f"{mismatch} pixels disagree on hit / miss"
     assert both.sum() > (400 if close else 20)
-    assert np.abs(want_t - got_t)[both].max() <= 2e-4
+    assert dt.max() <= 2e-4
 
 
 def test_two_crater_balls_in_one_scene(alg, oracle, golden):
