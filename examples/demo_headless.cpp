@@ -1,7 +1,10 @@
 // The demo's default scene and camera, rendered headlessly through the C++ scene / render API:
 // a crater ball lit by a large emissive slab, viewed through a 10-degree lens from 30 units away.
 //
-//   demo_headless [width height spp bounces seed out.img [passes]]
+//   demo_headless [width height spp bounces seed out.img [passes [resume_after]]]
+//
+// resume_after > 0: after that many passes the accumulator is saved (ProgressiveFrame::save, `out`.ckpt), everything
+// is torn down, and a new Renderer and ProgressiveFrame load the checkpoint and render the remaining passes.
 //
 // Writes the frame with Image::save (u64 width, u64 height, row-major f32 rgb) and prints timing.
 // Renderer::render runs on the GPU; nothing here has a CPU fallback.
@@ -30,6 +33,7 @@ int main(int argc, char** argv) {
     // more than one pass: the demo's progressive loop with the accumulator on the GPU (ProgressiveFrame); writes the
     // mean image to `out` and the displayed bytes to `out`.rgba
     const std::size_t passes = argc > 7 ? std::strtoul(argv[7], nullptr, 10) : 1;
+    const std::size_t resume_after = argc > 8 ? std::strtoul(argv[8], nullptr, 10) : 0;
 
     // The demo draws its noise transform at random per process; fix it here.
     const Affine noise = Affine::Translation(Vec(0.417022f, 0.720324f, 0.000114f)) * Linear::RotationX(0.302333f) *
@@ -69,6 +73,29 @@ int main(int argc, char** argv) {
     settings.setNumBounces(bounces);
     settings.setSamplesPerPixel(spp);
 
+    if (passes > 1 && resume_after > 0 && resume_after < passes) {
+        const std::string ckpt = out + ".ckpt";
+        {
+            auto first = Renderer{};
+            first.startThreadPool();
+            first.setSeed(seed);
+            ProgressiveFrame acc(width, height);
+            for (std::size_t i = 0; i < resume_after; ++i) acc.add(first, scene, camera, settings);
+            acc.save(ckpt, first);
+        }
+        auto second = Renderer{};   // a fresh renderer: its seed and frame counter come from the checkpoint
+        second.startThreadPool();
+        ProgressiveFrame acc(width, height);
+        if (!acc.load(ckpt, second)) {
+            std::fprintf(stderr, "checkpoint %s did not load\n", ckpt.c_str());
+            return 1;
+        }
+        for (std::size_t i = resume_after; i < passes; ++i) acc.add(second, scene, camera, settings);
+        acc.image().save(out);
+        std::printf("%zu passes of %zu spp, saved after %zu and resumed from %s (%zu passes counted), wrote %s\n", passes, spp, resume_after, ckpt.c_str(),
+                    acc.count(), out.c_str());
+        return 0;
+    }
     auto renderer = Renderer{};
     renderer.startThreadPool();
     renderer.setSeed(seed);

@@ -199,6 +199,8 @@ int  mipt_scale_device(mipt_ctx*, const float* device_in, float k, size_t n_floa
 int  mipt_device_floats_alloc(mipt_ctx*, size_t n, float** out);
 int  mipt_device_floats_zero(mipt_ctx*, float* p, size_t n);
 int  mipt_device_floats_read(mipt_ctx*, const float* p, float k, size_t n, float* host_out);
+/* host -> device: puts a saved accumulator back (resume from an Image file, src/Image.cpp:62-81) */
+int  mipt_device_floats_write(mipt_ctx*, float* p, size_t n, const float* host_in);
 void mipt_device_floats_free(mipt_ctx*, float* p);
 /* The display step of the demo's progressive loop (PathTracerDemo.cpp:963-971: `acc += rendered`,
  * scaleImage(acc, 1 / count), tone map, copyToSFImage :524-545) for an accumulator that stays on the

@@ -17,6 +17,7 @@
 
 #include <array>
 #include <atomic>
+#include <barrier>   // the reference's Renderer.hpp includes <barrier> and <thread>; programs written against it
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -25,6 +26,7 @@
 #include <optional>
 #include <random>
 #include <string>
+#include <thread>    // (PathTracerDemo.cpp uses std::thread through that include)
 #include <typeinfo>
 #include <utility>
 #include <vector>
@@ -723,6 +725,13 @@ public:
     // copyToSFImage's bytes (PathTracerDemo.cpp:524-545: clamp to [0, 1], times 255, truncated; R, G, B, 255) of the mean,
     // through no tone mapper (-1, as the demo shows it), Reinhard (0) or filmic (1); rgba holds width * height * 4 bytes
     void present(std::uint8_t* rgba, int toneMapper = -1) const;
+    // Checkpoint and resume.  save() writes the radiance sums in Image's raw format (Image::load -- the reference's too --
+    // reads the file as an image of sums) followed by the sample count and the renderer's position in its sample sequence;
+    // load() puts them back (false, and nothing changed, if the file is a plain image or of another size; throws as
+    // Image::load does if it cannot be opened).  A frame that is saved, loaded and continued equals the uninterrupted
+    // one bit for bit.
+    void save(const std::string& path, const Renderer&) const;
+    bool load(const std::string& path, Renderer&);
 
 private:
     std::size_t m_width, m_height, m_count = 0;

@@ -55,7 +55,7 @@ EXPORTS = [
     "mipt_scene_free", "mipt_scene_info", "mipt_render", "mipt_render_accumulate", "mipt_scale_device",
     "mipt_primary_hits", "mipt_trace_rays", "mipt_tonemap", "mipt_tonemap_device", "mipt_affine_inverse",
     "mipt_rotation", "mipt_affine_mul", "mipt_noise_transform", "mipt_world_bounds", "mipt_present_rgba8",
-    "mipt_tonemap_device_noalloc", "mipt_trim", "mipt_sdf_eval", "mipt_set_counting",
+    "mipt_tonemap_device_noalloc", "mipt_trim", "mipt_sdf_eval", "mipt_set_counting", "mipt_device_floats_write",
 ]
 
 _dll = None
@@ -82,6 +82,7 @@ def dll():
         d.mipt_device_floats_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         d.mipt_device_floats_zero.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         d.mipt_device_floats_read.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_size_t, _f32p]
+        d.mipt_device_floats_write.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, _f32p]
         d.mipt_device_floats_free.argtypes = [C.c_void_p, C.c_void_p]
         d.mipt_device_floats_free.restype = None
         d.mipt_scene_free.argtypes = [C.c_void_p]

@@ -997,6 +997,15 @@ int mipt_device_floats_read(mipt_ctx* c, const float* p, float k, size_t n, floa
     return MIPT_OK;
 }
 
+int mipt_device_floats_write(mipt_ctx* c, float* p, size_t n, const float* host_in) {
+    if (!c || !p || !host_in || n == 0) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(p, host_in, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MIPT_OK;
+}
+
 void mipt_device_floats_free(mipt_ctx* c, float* p) {
     if (!c || !p) return;
     std::lock_guard<std::mutex> lock(c->mutex);

@@ -7,6 +7,8 @@
 #include "pathtracer/pathtracer.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <cassert>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -264,14 +266,25 @@ Vec randomPointOnHemisphereCosine(Vec normal) noexcept {   // :320-341
 // ================================================================================================
 BasicMaterial::BasicMaterial() noexcept : m_p{0.3f, 0.3f, 0.9f, 1.0f, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.5f, 0.9f, 0.9f, 0.9f} {}   // :9-18
 
-void BasicMaterial::setDiffuseReflection(float r) noexcept { m_p[0] = r; }
-void BasicMaterial::setSpecularReflection(float r) noexcept { m_p[1] = r; }
-void BasicMaterial::setSpecularSharpness(float r) noexcept { m_p[2] = r; }
-void BasicMaterial::setReflectedAbsorption(Color c) noexcept { m_p[3] = c.r; m_p[4] = c.g; m_p[5] = c.b; }
+// The setters assert their ranges as the reference's do (src/BasicMaterial.cpp:54-95); like the reference's default
+// build, this library is compiled without NDEBUG, so the asserts are live.
+namespace {
+inline bool unit_range(float v) { return v >= 0.0f && v <= 1.0f; }
+}
+void BasicMaterial::setDiffuseReflection(float r) noexcept { assert(unit_range(r)); m_p[0] = r; }
+void BasicMaterial::setSpecularReflection(float r) noexcept { assert(unit_range(r)); m_p[1] = r; }
+void BasicMaterial::setSpecularSharpness(float r) noexcept { assert(unit_range(r)); m_p[2] = r; }
+void BasicMaterial::setReflectedAbsorption(Color c) noexcept {
+    assert(unit_range(c.r) && unit_range(c.g) && unit_range(c.b));
+    m_p[3] = c.r; m_p[4] = c.g; m_p[5] = c.b;
+}
 void BasicMaterial::setEmittedLuminance(Color c) noexcept { m_p[6] = c.r; m_p[7] = c.g; m_p[8] = c.b; }
-void BasicMaterial::setTransmittance(float r) noexcept { m_p[9] = r; }
-void BasicMaterial::setIndexOfRefraction(float i) noexcept { m_p[10] = i; }
-void BasicMaterial::setInternalAbsorption(Color c) noexcept { m_p[11] = c.r; m_p[12] = c.g; m_p[13] = c.b; }
+void BasicMaterial::setTransmittance(float r) noexcept { assert(unit_range(r)); m_p[9] = r; }
+void BasicMaterial::setIndexOfRefraction(float i) noexcept { assert(i >= 1.0f); m_p[10] = i; }
+void BasicMaterial::setInternalAbsorption(Color c) noexcept {
+    assert(unit_range(c.r) && unit_range(c.g) && unit_range(c.b));
+    m_p[11] = c.r; m_p[12] = c.g; m_p[13] = c.b;
+}
 
 // Inside hits are deterministic; outside hits pick diffuse / specular / transmission with probabilities
 // proportional to the three weights; every lobe returns the emitted luminance and the reflected
@@ -633,6 +646,9 @@ mipt_ctx* shared_context() {
 }
 
 struct SceneDeviceState {
+    // Renderer::render takes its scene by const reference and the reference's is safe for concurrent readers
+    // (src/Renderer.cpp:139-172); here a render refreshes the device copy first, so renders of one scene are serialised.
+    std::mutex mutex;
     mipt_scene* scene = nullptr;
     std::vector<uint32_t> kind, material;
     std::vector<float> fwd, inv, params, materials;
@@ -647,9 +663,28 @@ struct RendererState {
     std::uint64_t seed = 0x5eed;
     std::uint64_t frame = 0;
     bool started = false;
+    // Every Renderer drives the GPU through a context of its own (its own stream, working set and cancel flag), so
+    // cancelRender() stops this renderer's frame and no other's; scenes and tone mappers use the shared context of
+    // the same device.
+    std::atomic<mipt_ctx*> ctx{nullptr};
+    mipt_ctx* context() {   // caller holds `mutex`
+        mipt_ctx* c = ctx.load(std::memory_order_acquire);
+        if (!c) {
+            int device = 0;
+            if (const char* e = std::getenv("MIPT_DEVICE")) device = std::atoi(e);
+            const int rc = mipt_init(device, nullptr, &c);
+            if (rc != MIPT_OK) fail("mipt_init", rc);
+            ctx.store(c, std::memory_order_release);
+        }
+        return c;
+    }
+    ~RendererState() {
+        if (mipt_ctx* c = ctx.load()) mipt_shutdown(c);
+    }
 };
 
 // Flattens the objects (Scene::updateGeometry's job in this design) and uploads when anything changed.
+// The caller holds the scene's device-state lock until it has finished rendering from the returned scene.
 mipt_scene* sync_scene(const Scene& scene) {
     SceneDeviceState& st = scene.deviceState();
     const auto& objs = scene.objects();
@@ -778,10 +813,13 @@ Ray Camera::getViewRay(float screenX, float screenY) const noexcept {   // src/C
     return Ray((m_transform * view).unit(), m_transform * (sp - blur));
 }
 
-RenderSettings::RenderSettings(std::size_t w, std::size_t h) noexcept : m_width(w), m_height(h), m_numBounces(8), m_samplesPerPixel(1) {}
-void RenderSettings::setSize(size_t w, size_t h) noexcept { m_width = w; m_height = h; }
-void RenderSettings::setNumBounces(std::size_t n) noexcept { m_numBounces = n; }
-void RenderSettings::setSamplesPerPixel(std::size_t s) noexcept { m_samplesPerPixel = s; }
+RenderSettings::RenderSettings(std::size_t w, std::size_t h) noexcept : m_width(w), m_height(h), m_numBounces(8), m_samplesPerPixel(1) {
+    assert(m_width > 0 && m_height > 0);
+}
+// asserted as in src/RenderSettings.cpp:5-47
+void RenderSettings::setSize(size_t w, size_t h) noexcept { assert(w > 0 && h > 0); m_width = w; m_height = h; }
+void RenderSettings::setNumBounces(std::size_t n) noexcept { assert(n > 0); m_numBounces = n; }
+void RenderSettings::setSamplesPerPixel(std::size_t s) noexcept { assert(s > 0); m_samplesPerPixel = s; }
 
 Image::Image(std::size_t w, std::size_t h) : m_width(w), m_height(h), m_data(w * h, Color{}) {}
 
@@ -814,11 +852,13 @@ Image& Image::operator+=(const Image& other) noexcept {
 // ================================================================================================
 // renderer (src/Renderer.cpp)
 // ================================================================================================
-Renderer::Renderer() noexcept : m_state(new (std::nothrow) mipt_host::RendererState) {}
+Renderer::Renderer() noexcept : m_state(new mipt_host::RendererState) {}   // (noexcept as in the reference: failing to allocate terminates)
 Renderer::~Renderer() = default;
 
 void Renderer::startThreadPool(size_t) {
+    std::lock_guard<std::mutex> lock(m_state->mutex);
     mipt_host::shared_context();
+    m_state->context();
     m_state->started = true;
 }
 void Renderer::stopThreadPool() { m_state->started = false; }
@@ -849,7 +889,8 @@ mipt_settings next_frame_settings(mipt_host::RendererState& rs, const RenderSett
 
 Image Renderer::render(const Scene& scene, const Camera& camera, const RenderSettings& settings) {
     std::lock_guard<std::mutex> lock(m_state->mutex);
-    mipt_ctx* ctx = mipt_host::shared_context();
+    mipt_ctx* ctx = m_state->context();
+    std::lock_guard<std::mutex> scene_lock(scene.deviceState().mutex);
     mipt_scene* dev = mipt_host::sync_scene(scene);
     const mipt_camera cam = pack_camera(camera);
     const mipt_settings st = next_frame_settings(*m_state, settings);
@@ -859,7 +900,9 @@ Image Renderer::render(const Scene& scene, const Camera& camera, const RenderSet
     return img;
 }
 
-void Renderer::cancelRender() noexcept { mipt_cancel(mipt_host::shared_context()); }
+void Renderer::cancelRender() noexcept {   // any thread, lock-free (src/Renderer.cpp:174-176)
+    if (mipt_ctx* c = m_state->ctx.load(std::memory_order_acquire)) mipt_cancel(c);
+}
 
 void Renderer::setSeed(std::uint64_t seed) noexcept {
     m_state->seed = seed;
@@ -886,7 +929,8 @@ void ProgressiveFrame::reset() {
 bool ProgressiveFrame::add(Renderer& renderer, const Scene& scene, const Camera& camera, const RenderSettings& settings) {
     if (settings.width() != m_width || settings.height() != m_height) mipt_host::fail("ProgressiveFrame::add: the settings' size is not the frame's", MIPT_ERR_ARGUMENT);
     std::lock_guard<std::mutex> lock(renderer.m_state->mutex);
-    mipt_ctx* ctx = mipt_host::shared_context();
+    mipt_ctx* ctx = renderer.m_state->context();
+    std::lock_guard<std::mutex> scene_lock(scene.deviceState().mutex);
     mipt_scene* dev = mipt_host::sync_scene(scene);
     const mipt_camera cam = pack_camera(camera);
     const mipt_settings st = next_frame_settings(*renderer.m_state, settings);
@@ -895,6 +939,47 @@ bool ProgressiveFrame::add(Renderer& renderer, const Scene& scene, const Camera&
     if (rc != MIPT_OK) mipt_host::fail("mipt_render_accumulate", rc);
     m_samples += settings.samplesPerPixel();
     m_count += 1;
+    return true;
+}
+
+// Checkpoint: the radiance SUMS in Image's raw format (src/Image.cpp:48-60: u64 width, u64 height, row-major f32 r, g, b),
+// so Image::load reads the file -- the reference's too, which stops after the pixels -- followed by five u64: a tag,
+// the samples per pixel and passes accumulated, and the renderer's seed and frame counter (which sample indices come next).
+namespace {
+constexpr std::uint64_t kCheckpointTag = 0x3143434154504d4dull;   // "MMPTACC1"
+}
+
+void ProgressiveFrame::save(const std::string& path, const Renderer& renderer) const {
+    Image sums(m_width, m_height);
+    const int rc = mipt_device_floats_read(mipt_host::shared_context(), m_device, 1.0f, m_width * m_height * 3, sums.raw());
+    if (rc != MIPT_OK) mipt_host::fail("mipt_device_floats_read", rc);
+    sums.save(path);
+    std::ofstream f(path, std::ios::out | std::ios::binary | std::ios::app);
+    std::uint64_t seed, frame;
+    {
+        std::lock_guard<std::mutex> lock(renderer.m_state->mutex);
+        seed = renderer.m_state->seed;
+        frame = renderer.m_state->frame;
+    }
+    const std::uint64_t tail[5] = {kCheckpointTag, m_samples, m_count, seed, frame};
+    f.write(reinterpret_cast<const char*>(tail), sizeof(tail));
+}
+
+bool ProgressiveFrame::load(const std::string& path, Renderer& renderer) {
+    const Image sums = Image::load(path);   // throws std::runtime_error when the file cannot be opened, as Image::load does
+    if (sums.width() != m_width || sums.height() != m_height) return false;
+    std::ifstream f(path, std::ios::in | std::ios::binary);
+    f.seekg(static_cast<std::streamoff>(16 + m_width * m_height * 12));
+    std::uint64_t tail[5] = {};
+    f.read(reinterpret_cast<char*>(tail), sizeof(tail));
+    if (!f || tail[0] != kCheckpointTag) return false;   // a plain image, not a checkpoint
+    const int rc = mipt_device_floats_write(mipt_host::shared_context(), m_device, m_width * m_height * 3, sums.raw());
+    if (rc != MIPT_OK) mipt_host::fail("mipt_device_floats_write", rc);
+    m_samples = tail[1];
+    m_count = static_cast<std::size_t>(tail[2]);
+    std::lock_guard<std::mutex> lock(renderer.m_state->mutex);
+    renderer.m_state->seed = tail[3];
+    renderer.m_state->frame = tail[4];
     return true;
 }
 

@@ -29,7 +29,7 @@ def ctx():
 def _load_image(path):
     raw = open(path, "rb").read()
     w, h = np.frombuffer(raw[:16], np.uint64)
-    return np.frombuffer(raw[16:], np.float32).reshape(int(h), int(w), 3)
+    return np.frombuffer(raw[16:16 + int(w) * int(h) * 12], np.float32).reshape(int(h), int(w), 3)   # (a checkpoint carries a trailer)
 
 
 def test_headless_demo_program_matches_c_abi(ctx, tmp_path):
@@ -109,3 +109,27 @@ def test_progressive_frame_keeps_the_accumulator_on_the_device(ctx, tmp_path):
     assert np.array_equal(got, want) and want.max() > 0
     assert np.array_equal(rgba[..., :3], (np.clip(want, 0.0, 1.0) * np.float32(255.0)).astype(np.uint8))
     assert (rgba[..., 3] == 255).all()
+
+
+def test_progressive_frame_resumes_from_a_checkpoint(ctx, tmp_path):
+    """ProgressiveFrame::save / load (Image's raw format, src/Image.cpp:48-81, + the sample count and the renderer's
+    position in its sample sequence): four passes of 3 spp, saved after the second and resumed by a new Renderer and a
+    new frame, equal the uninterrupted 12-spp frame bit for bit; the checkpoint itself reads as an Image of sums."""
+    exe = os.path.join(LIB, "demo_headless")
+    if not os.path.exists(exe):
+        pytest.skip("demo_headless not built (make -C pathtracer_amd/host example)")
+    out = tmp_path / "resumed.img"
+    r = subprocess.run([exe, "96", "64", "3", "8", "9", str(out), "4", "2"], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stderr
+    assert "(4 passes counted)" in r.stdout
+    got = _load_image(out)
+    alg = api.HostAlgebra()
+    ds = ctx.upload(S.demo_scene(alg))
+    cam = S.demo_camera(alg, 96 / 64)
+    want, _ = ctx.render(ds, cam, 96, 64, 8, 12, seed=9)
+    assert np.array_equal(got, want) and want.max() > 0
+    half, _ = ctx.render(ds, cam, 96, 64, 8, 6, seed=9)
+    sums = _load_image(str(out) + ".ckpt")            # the file's head is a plain Image: the sums after two passes
+    assert np.allclose(sums, half * 6.0, rtol=1e-6, atol=1e-7)
+    tail = np.fromfile(str(out) + ".ckpt", np.uint64, offset=16 + 96 * 64 * 12)
+    assert tail.shape == (5,) and tail[1] == 6 and tail[2] == 2 and tail[3] == 9 and tail[4] == 2
