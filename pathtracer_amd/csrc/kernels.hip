@@ -436,37 +436,29 @@ __device__ __forceinline__ void trav_inner_step(const SceneDev& sc, Trav& t, int
     const float4 a = np[0], b = np[1], c = np[2], e = np[3];
     const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y};
     const float lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
-    int c0 = __float_as_int(e.x), c1 = __float_as_int(e.y);
+    const int c0 = __float_as_int(e.x), c1 = __float_as_int(e.y);
     float t0, t1;
-    bool h0 = slab(t.o, t.inv_d, lo0, hi0, t.limit, t0);
-    bool h1 = slab(t.o, t.inv_d, lo1, hi1, t.limit, t1);
-    if (h0 && h1 && t1 < t0) {   // nearer child first
-        const int tc = c0; c0 = c1; c1 = tc;
-        const float tt = t0; t0 = t1; t1 = tt;
-    } else if (!h0 && h1) {
-        c0 = c1; t0 = t1; h0 = true; h1 = false;
-    }
-    t.cur = kTravNone;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const bool h = side == 0 ? h0 : h1;
-        const int ch = side == 0 ? c0 : c1;
-        const float tn = side == 0 ? t0 : t1;
-        if (!h) continue;
-        if (ch < 0) {   // leaf ~ch
-            if (t.leaf0 == kTravNone) {
-                t.leaf0 = ~ch;
-            } else {
-                t.leaf1 = ~ch;
-                t.tn_leaf1 = tn;
-            }
-        } else if (t.cur == kTravNone) {
-            t.cur = ch;
-            t.tn_cur = tn;
-        } else {
-            stack[t.sp * 256] = ch;
-            ++t.sp;
-        }
+    const bool h0 = slab(t.o, t.inv_d, lo0, hi0, t.limit, t0);
+    const bool h1 = slab(t.o, t.inv_d, lo1, hi1, t.limit, t1);
+    // Everything below is selects rather than branches: the lanes of a wave take every combination of
+    // hit / miss and leaf / node at once, and a branch per case costs more than computing all of them.
+    // Order the children, the nearer hit first (a lone hit counts as the first).
+    const bool sw = h1 && (!h0 || t1 < t0);
+    const int ca = sw ? c1 : c0, cb = sw ? c0 : c1;
+    const float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
+    const bool ha = h0 || h1, hb = h0 && h1;
+    const bool leaf_a = ha && ca < 0, node_a = ha && ca >= 0;
+    const bool leaf_b = hb && cb < 0, node_b = hb && cb >= 0;
+    // hit leaves become the lane's pending leaves (none is pending on entry), hit nodes: one is visited next ...
+    t.leaf0 = leaf_a ? ~ca : (leaf_b ? ~cb : kTravNone);
+    t.leaf1 = (leaf_a && leaf_b) ? ~cb : kTravNone;
+    t.tn_leaf1 = tb;
+    t.cur = node_a ? ca : (node_b ? cb : kTravNone);
+    t.tn_cur = node_a ? ta : tb;
+    // ... and the other goes on the lane's stack
+    if (node_a && node_b) {
+        stack[t.sp * 256] = cb;
+        ++t.sp;
     }
     if (t.leaf0 == kTravNone) trav_advance(t, stack);
 }
