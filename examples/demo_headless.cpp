@@ -1,14 +1,18 @@
 // The demo's default scene and camera, rendered headlessly through the C++ scene / render API:
 // a crater ball lit by a large emissive slab, viewed through a 10-degree lens from 30 units away.
 //
-//   demo_headless [width height spp bounces seed out.img [passes [resume_after]]]
+//   demo_headless [width height spp bounces seed out.img [passes [resume_after [user]]]]
 //
 // resume_after > 0: after that many passes the accumulator is saved (ProgressiveFrame::save, `out`.ckpt), everything
 // is torn down, and a new Renderer and ProgressiveFrame load the checkpoint and render the remaining passes.
 //
+// With a ninth argument "user" the light is not a BoxObject but an Object subclass defined in this file (UserSlab): the
+// library has no device form for it and evaluates it through its virtuals on the host (the slow path).
+//
 // Writes the frame with Image::save (u64 width, u64 height, row-major f32 rgb) and prints timing.
 // Renderer::render runs on the GPU; nothing here has a CPU fallback.
 #include <Camera.hpp>
+#include <Geometry.hpp>
 #include <Image.hpp>
 #include <Object.hpp>
 #include <Renderer.hpp>
@@ -23,6 +27,20 @@
 #include <vector>
 #include <string>
 
+// What any user of the reference may write: an Object subclass with its own three virtuals (include/Object.hpp:45-52).
+// This one is a box like BoxObject, so that a frame lit by it can be compared with the ordinary one.
+class UserSlab : public Object {
+public:
+    UserSlab(Rectangle geometry, BasicMaterial material) noexcept : m_geometry(geometry), m_material(material) {}
+
+private:
+    std::optional<Pos> hitLocalRay(const Ray& ray) const noexcept override { return intersect(ray, m_geometry); }
+    ColorBounce deflectLocalRay(const Ray& ray) const noexcept override { return m_material.deflect(ray.dir, m_geometry.normal(ray.pos)); }
+    AxisAlignedBox getLocalBoundingBox() const noexcept override { return AxisAlignedBox{Pos(0.0f, 0.0f, 0.0f), m_geometry.halfSize + Vec(1e-3f, 1e-3f, 1e-3f)}; }
+    Rectangle m_geometry;
+    BasicMaterial m_material;
+};
+
 int main(int argc, char** argv) {
     const std::size_t width = argc > 1 ? std::strtoul(argv[1], nullptr, 10) : 256;
     const std::size_t height = argc > 2 ? std::strtoul(argv[2], nullptr, 10) : 256;
@@ -34,6 +52,7 @@ int main(int argc, char** argv) {
     // mean image to `out` and the displayed bytes to `out`.rgba
     const std::size_t passes = argc > 7 ? std::strtoul(argv[7], nullptr, 10) : 1;
     const std::size_t resume_after = argc > 8 ? std::strtoul(argv[8], nullptr, 10) : 0;
+    const bool user_light = argc > 9 && std::string(argv[9]) == "user";
 
     // The demo draws its noise transform at random per process; fix it here.
     const Affine noise = Affine::Translation(Vec(0.417022f, 0.720324f, 0.000114f)) * Linear::RotationX(0.302333f) *
@@ -57,8 +76,13 @@ int main(int argc, char** argv) {
         m.setTransmittance(0.0f);
         m.setReflectedAbsorption(Color{1.0f, 1.0f, 1.0f});
         m.setEmittedLuminance(2.0f * Color{1.0f, 1.0f, 1.0f});
-        auto& slab = scene.addObject<BoxObject>(Rectangle(Vec(100.0f, 0.1f, 100.0f)), m);
-        slab.setTransformation(Affine::Translation(Vec{0.0f, -50.0f, 0.0f}));
+        if (user_light) {
+            auto& slab = scene.addObject<UserSlab>(Rectangle(Vec(100.0f, 0.1f, 100.0f)), m);
+            slab.setTransformation(Affine::Translation(Vec{0.0f, -50.0f, 0.0f}));
+        } else {
+            auto& slab = scene.addObject<BoxObject>(Rectangle(Vec(100.0f, 0.1f, 100.0f)), m);
+            slab.setTransformation(Affine::Translation(Vec{0.0f, -50.0f, 0.0f}));
+        }
     }
     scene.updateGeometry();
 

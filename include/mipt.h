@@ -38,7 +38,12 @@ typedef struct mipt_scene mipt_scene;
  * (:156-226) and WeirdWallObject (:273-349). */
 enum {
     MIPT_SPHERE = 0, MIPT_BOX = 1, MIPT_TRIANGLE = 2, MIPT_CRATERBALL = 3, MIPT_FRACTAL = 4, MIPT_ROUGHBOX = 5,
-    MIPT_ROUGHSPHERE = 6, MIPT_WEIRDWALL = 7
+    MIPT_ROUGHSPHERE = 6, MIPT_WEIRDWALL = 7,
+    /* Any other Object subclass (include/Object.hpp:45-52: hitLocalRay, deflectLocalRay, getLocalBoundingBox overridden by
+     * the user).  It has no device form: rays that reach its bounding box are handed to the host, which evaluates the
+     * object through the callbacks of mipt_scene_upload_host; params = the object's getBoundingBox() (the padded WORLD
+     * box, src/Object.cpp:46-80) as {centre x,y,z, half size x,y,z}; fwd / inv are not used. */
+    MIPT_HOST_OBJECT = 8
 };
 
 /* What Scene::updateGeometry (src/Scene.cpp:80-87) flattens its objects into.  Arrays are copied
@@ -125,6 +130,9 @@ typedef struct {
      * (src/ObjectTree.cpp:22-63), rays * objects. */
     uint64_t node_visits;
     uint64_t prim_tests;
+    /* The slow path of scenes with MIPT_HOST_OBJECT primitives: Object::hitRay and Object::deflectRay calls made on the host. */
+    uint64_t host_rays;
+    uint64_t host_shades;
 } mipt_stats;
 
 enum { MIPT_STAGE_GENERATE = 0, MIPT_STAGE_EXTEND = 1, MIPT_STAGE_SDF_MARCH = 2, MIPT_STAGE_SHADE = 3,
@@ -174,6 +182,21 @@ int  mipt_scene_upload(mipt_ctx*, const mipt_scene_desc*, mipt_scene** out);
  * (MIPT_ERR_ARGUMENT), more than 60 tree levels (only a great many coincident objects get there) with MIPT_ERR_TOO_LARGE. */
 enum { MIPT_UPLOAD_DEVICE_BVH = 1u };
 int  mipt_scene_upload_ex(mipt_ctx*, const mipt_scene_desc*, uint32_t flags, mipt_scene** out);
+/* Scenes that hold MIPT_HOST_OBJECT primitives.  The callbacks stand for the object's non-virtual wrappers
+ * Object::hitRay (src/Object.cpp:22-33: world ray in; returns nonzero and the world hit position on a hit) and
+ * Object::deflectRay (src/Object.cpp:35-44: ray_pos = the hit position, ray_dir = the incoming direction; out9 = emitted
+ * r,g,b, attenuation r,g,b, new direction in world space), `prim` being the primitive's index in the scene description.
+ * They are called from several threads of the library at once while a render call runs (the reference calls the same
+ * virtuals from its worker threads) and must stay valid until mipt_scene_free.  This is the slow path: every bounce
+ * of a frame costs two round trips to the host; mipt_stats::host_rays / host_shades report how much went that way.
+ * Everything else about the frame -- closest hit over all objects, ties to the lower index, Scene::trace's
+ * accumulation -- is as for device primitives. */
+typedef struct {
+    int  (*hit)(void* user, uint32_t prim, const float ray_pos[3], const float ray_dir[3], float out_hit_pos[3]);
+    void (*deflect)(void* user, uint32_t prim, const float ray_pos[3], const float ray_dir[3], float out9[9]);
+    void* user;
+} mipt_host_callbacks;
+int  mipt_scene_upload_host(mipt_ctx*, const mipt_scene_desc*, uint32_t flags, const mipt_host_callbacks*, mipt_scene** out);
 void mipt_scene_free(mipt_scene*);
 /* BVH facts for tests and reports: out4 = node count, depth, analytic primitives, SDF primitives. */
 int  mipt_scene_info(const mipt_scene*, uint32_t out4[4]);

@@ -65,7 +65,9 @@ UPLOAD_DEVICE_BVH = 1
 
 
 class DeviceScene:
-    def __init__(self, ctx, flat, flags=None):
+    def __init__(self, ctx, flat, flags=None, host_hit=None, host_deflect=None):
+        """host_hit(prim, pos3, dir3) -> hit position (3 floats) or None, host_deflect(prim, pos3, dir3) -> 9 floats
+        (emitted, attenuation, world direction): the callbacks of the scene's MIPT_HOST_OBJECT primitives (kind 8)."""
         self.ctx = ctx
         self._keep = [np.ascontiguousarray(flat.kind, np.uint32), f32(flat.fwd), f32(flat.inv), f32(flat.params),
                       np.ascontiguousarray(flat.material, np.uint32), f32(flat.materials), f32(flat.noise)]
@@ -73,7 +75,22 @@ class DeviceScene:
         d = capi.SceneDesc(k.shape[0], k.ctypes.data_as(capi._u32p), fp(fwd), fp(inv), fp(par),
                            mat.ctypes.data_as(capi._u32p), mats.shape[0], fp(mats), fp(noise))
         h = C.c_void_p()
-        if flags is None:
+        if host_hit is not None:
+            def _hit(_user, prim, pos, dirs, out):
+                r = host_hit(int(prim), np.ctypeslib.as_array(pos, (3,)).copy(), np.ctypeslib.as_array(dirs, (3,)).copy())
+                if r is None:
+                    return 0
+                out[0], out[1], out[2] = float(r[0]), float(r[1]), float(r[2])
+                return 1
+
+            def _deflect(_user, prim, pos, dirs, out):
+                r = host_deflect(int(prim), np.ctypeslib.as_array(pos, (3,)).copy(), np.ctypeslib.as_array(dirs, (3,)).copy())
+                for k in range(9):
+                    out[k] = float(r[k])
+
+            self._cb = capi.HostCallbacks(capi.HIT_FN(_hit), capi.DEFLECT_FN(_deflect), None)   # kept alive with the scene
+            check(capi.dll().mipt_scene_upload_host(ctx.h, C.byref(d), int(flags or 0), C.byref(self._cb), C.byref(h)), "mipt_scene_upload_host")
+        elif flags is None:
             check(capi.dll().mipt_scene_upload(ctx.h, C.byref(d), C.byref(h)), "mipt_scene_upload")
         else:
             check(capi.dll().mipt_scene_upload_ex(ctx.h, C.byref(d), int(flags), C.byref(h)), "mipt_scene_upload_ex")
@@ -113,9 +130,9 @@ class Context:
         except Exception:   # noqa: BLE001
             pass
 
-    def upload(self, flat, device_bvh=None):
+    def upload(self, flat, device_bvh=None, host_hit=None, host_deflect=None):
         """device_bvh: None = the library's default (host build unless MIPT_DEVICE_BVH=1), True/False = explicit."""
-        return DeviceScene(self, flat, None if device_bvh is None else (UPLOAD_DEVICE_BVH if device_bvh else 0))
+        return DeviceScene(self, flat, None if device_bvh is None else (UPLOAD_DEVICE_BVH if device_bvh else 0), host_hit, host_deflect)
 
     def set_profiling(self, on):
         check(capi.dll().mipt_set_profiling(self.h, 1 if on else 0), "mipt_set_profiling")
@@ -144,7 +161,8 @@ class Context:
                     stage_ms=dict(zip(STAGES, (float(x) for x in st.stage_ms))),
                     stage_launches=dict(zip(STAGES, (int(x) for x in st.stage_launches))),
                     primary_traced=int(st.primary_traced), samples_done=int(st.samples_done),
-                    node_visits=int(st.node_visits), prim_tests=int(st.prim_tests))
+                    node_visits=int(st.node_visits), prim_tests=int(st.prim_tests),
+                    host_rays=int(st.host_rays), host_shades=int(st.host_shades))
 
     def render(self, scene, cam16, w, h, bounces, spp, seed=1, first_sample=0, flags=0):
         """Renderer::render: (h, w, 3) float32 mean image and the call's statistics."""

@@ -46,7 +46,16 @@ class Stats(C.Structure):
                 ("shade_evals", C.c_uint64), ("shade_noise_calls", C.c_uint64),
                 ("ms_device", C.c_double), ("stage_ms", C.c_double * 6), ("stage_launches", C.c_uint64 * 6),
                 ("primary_traced", C.c_uint64), ("samples_done", C.c_uint64),
-                ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64)]
+                ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64),
+                ("host_rays", C.c_uint64), ("host_shades", C.c_uint64)]
+
+
+HIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, _f32p, _f32p, _f32p)
+DEFLECT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, _f32p, _f32p, _f32p)
+
+
+class HostCallbacks(C.Structure):
+    _fields_ = [("hit", HIT_FN), ("deflect", DEFLECT_FN), ("user", C.c_void_p)]
 
 
 EXPORTS = [
@@ -55,7 +64,7 @@ EXPORTS = [
     "mipt_scene_free", "mipt_scene_info", "mipt_render", "mipt_render_accumulate", "mipt_scale_device",
     "mipt_primary_hits", "mipt_trace_rays", "mipt_tonemap", "mipt_tonemap_device", "mipt_affine_inverse",
     "mipt_rotation", "mipt_affine_mul", "mipt_noise_transform", "mipt_world_bounds", "mipt_present_rgba8",
-    "mipt_tonemap_device_noalloc", "mipt_trim", "mipt_sdf_eval", "mipt_set_counting", "mipt_device_floats_write",
+    "mipt_tonemap_device_noalloc", "mipt_trim", "mipt_sdf_eval", "mipt_set_counting", "mipt_device_floats_write", "mipt_scene_upload_host",
 ]
 
 _dll = None
@@ -79,6 +88,7 @@ def dll():
         d.mipt_set_counting.argtypes = [C.c_void_p, C.c_int]
         d.mipt_scene_upload.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         d.mipt_scene_upload_ex.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.c_uint32, C.POINTER(C.c_void_p)]
+        d.mipt_scene_upload_host.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.c_uint32, C.POINTER(HostCallbacks), C.POINTER(C.c_void_p)]
         d.mipt_device_floats_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         d.mipt_device_floats_zero.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         d.mipt_device_floats_read.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_size_t, _f32p]

@@ -13,6 +13,7 @@
 #include <limits>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "bvh.h"
@@ -41,6 +42,10 @@ struct mipt_ctx {
     size_t vis_cap = 0;
     std::vector<uint32_t> vis_host;
     hipEvent_t batch_ev[2] = {nullptr, nullptr};   // end of the last two sample batches (at most two are queued at a time)
+    uint32_t* host_q = nullptr;      // PathBuffers::host_queue, allocated for scenes with host-evaluated objects
+    size_t host_q_cap = 0;
+    void* host_stage = nullptr;      // device staging of the host round trips (rays out, hits / bounces back)
+    size_t host_stage_cap = 0;       // bytes
     float* frame = nullptr;          // per-call radiance sum (mipt_render)
     size_t frame_cap = 0;
     float* tm_scratch = nullptr;     // Reinhard partials
@@ -75,6 +80,10 @@ struct mipt_scene {
     uint32_t n_nodes = 0, n_analytic = 0, n_sdf = 0;
     int depth = 0;
     std::vector<uint8_t> kinds;   // per primitive, for argument checks
+    // objects evaluated on the host: their primitive indices in the order of dev.host_boxes, the caller's callbacks
+    std::vector<uint32_t> host_prims;
+    mipt_host_callbacks host_cb{};
+    void* d_host_boxes = nullptr;
     // padded world boxes that together hold everything a ray can hit: the analytic primitives' common
     // box and the SDF primitives' boxes (merged into one if there are many)
     std::vector<std::array<float, 6>> cull_boxes;
@@ -311,21 +320,196 @@ struct StageTimer {
     }
 };
 
+// Runs body(i) for i in [0, n) on up to 16 threads (the user's virtuals are re-entrant, as the reference requires of them).
+template <class F>
+void host_parallel_for(uint32_t n, F&& body) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned threads = n < 256 ? 1u : std::min({16u, hw, n / 128u});
+    if (threads <= 1) {
+        for (uint32_t i = 0; i < n; ++i) body(i);
+        return;
+    }
+    std::atomic<uint32_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([&] {
+            for (;;) {
+                const uint32_t i0 = next.fetch_add(64);
+                if (i0 >= n) return;
+                for (uint32_t i = i0; i < std::min(n, i0 + 64u); ++i) body(i);
+            }
+        });
+    for (auto& th : pool) th.join();
+}
+
+int ensure_host_stage(mipt_ctx* c, size_t bytes) {
+    if (bytes <= c->host_stage_cap) return MIPT_OK;
+    if (c->host_stage) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(c->host_stage));
+        c->host_stage = nullptr;
+        c->host_stage_cap = 0;
+    }
+    const size_t cap = std::max(bytes, size_t(1) << 20);
+    const hipError_t e = hipMalloc(&c->host_stage, cap);
+    if (e != hipSuccess) {
+        c->last_hip = static_cast<int>(e);
+        return e == hipErrorOutOfMemory ? MIPT_ERR_OUT_OF_MEMORY : MIPT_ERR_HIP;
+    }
+    c->host_stage_cap = cap;
+    return MIPT_OK;
+}
+
+uint32_t ordered_float_bits(float t) {
+    uint32_t b;
+    std::memcpy(&b, &t, 4);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+
+// Closest hits on the objects that only the host can evaluate, for the live rays of `bounce` (after the device has
+// found their closest hit on everything else): per object, the rays that reach its box come to the host, the
+// object's hitRay runs on them, and hits that beat the ray's best are merged by key.  Synchronises the stream.
+int host_objects_extend(mipt_ctx* c, const mipt_scene* sc, uint32_t bounce, Totals& host_totals) {
+    for (uint32_t which = 0; which < sc->host_prims.size(); ++which) {
+        const uint32_t prim = sc->host_prims[which];
+        HIP_TRY(c, hipMemsetAsync(&c->pb.counters[bounce].n_host_rays, 0, sizeof(uint32_t), c->stream));
+        launch_host_gather(c->stream, sc->dev, c->pb, bounce, which);
+        uint32_t n = 0;
+        HIP_TRY(c, hipMemcpyAsync(&n, &c->pb.counters[bounce].n_host_rays, sizeof(n), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (n == 0 || c->cancel.load(std::memory_order_relaxed)) continue;
+        // staging: rays out (6 floats per ray); back: index, key, position per hit
+        const size_t bytes = static_cast<size_t>(n) * (24 + 4 + 8 + 12) + 64;
+        const int rc = ensure_host_stage(c, bytes);
+        if (rc != MIPT_OK) return rc;
+        char* base = static_cast<char*>(c->host_stage);
+        float* d_rays = reinterpret_cast<float*>(base);
+        unsigned long long* d_key = reinterpret_cast<unsigned long long*>(base + align_up(static_cast<size_t>(n) * 24, 8));
+        float* d_pos = reinterpret_cast<float*>(reinterpret_cast<char*>(d_key) + static_cast<size_t>(n) * 8);
+        uint32_t* d_idx = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(d_pos) + static_cast<size_t>(n) * 12);
+        launch_host_export_rays(c->stream, c->pb, n, d_rays);
+        std::vector<float> rays(static_cast<size_t>(n) * 6);
+        HIP_TRY(c, hipMemcpyAsync(rays.data(), d_rays, rays.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::vector<uint8_t> hit(n, 0);
+        std::vector<float> pos(static_cast<size_t>(n) * 3);
+        std::vector<unsigned long long> key(n);
+        host_parallel_for(n, [&](uint32_t i) {
+            const float* o = &rays[6 * static_cast<size_t>(i)];
+            const float* d = o + 3;
+            float* hp = &pos[3 * static_cast<size_t>(i)];
+            if (!sc->host_cb.hit(sc->host_cb.user, prim, o, d, hp)) return;
+            // t = (hit - ray.pos) . ray.dir, in the reference's order (src/ObjectTree.cpp:43-44); this file is compiled without contraction
+            const float dx = hp[0] - o[0], dy = hp[1] - o[1], dz = hp[2] - o[2];
+            const float t = dx * d[0] + dy * d[1] + dz * d[2];
+            key[i] = (static_cast<unsigned long long>(ordered_float_bits(t)) << 32) | prim;
+            hit[i] = 1;
+        });
+        host_totals.host_rays += n;
+        // compact the hits
+        uint32_t m = 0;
+        std::vector<uint32_t> idx(n);
+        for (uint32_t i = 0; i < n; ++i)
+            if (hit[i]) {
+                idx[m] = i;
+                key[m] = key[i];
+                pos[3 * static_cast<size_t>(m)] = pos[3 * static_cast<size_t>(i)];
+                pos[3 * static_cast<size_t>(m) + 1] = pos[3 * static_cast<size_t>(i) + 1];
+                pos[3 * static_cast<size_t>(m) + 2] = pos[3 * static_cast<size_t>(i) + 2];
+                ++m;
+            }
+        if (m == 0) continue;
+        HIP_TRY(c, hipMemcpyAsync(d_key, key.data(), static_cast<size_t>(m) * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_pos, pos.data(), static_cast<size_t>(m) * 12, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_idx, idx.data(), static_cast<size_t>(m) * 4, hipMemcpyHostToDevice, c->stream));
+        launch_host_merge(c->stream, c->pb, m, d_idx, d_key, d_pos);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));   // the host vectors go out of scope
+    }
+    return MIPT_OK;
+}
+
+// Object::deflectRay on the host for the hits of `bounce` that lie on host-evaluated objects (queued by shade).
+int host_objects_shade(mipt_ctx* c, const mipt_scene* sc, uint32_t bounce, uint32_t max_bounces, Totals& host_totals) {
+    uint32_t n = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n, &c->pb.counters[bounce].n_host_shade, sizeof(n), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n == 0 || c->cancel.load(std::memory_order_relaxed)) return MIPT_OK;
+    const int rc = ensure_host_stage(c, static_cast<size_t>(n) * (24 + 4 + 36) + 64);
+    if (rc != MIPT_OK) return rc;
+    char* base = static_cast<char*>(c->host_stage);
+    float* d_hits = reinterpret_cast<float*>(base);
+    uint32_t* d_prim = reinterpret_cast<uint32_t*>(base + static_cast<size_t>(n) * 24);
+    float* d_b9 = reinterpret_cast<float*>(base + static_cast<size_t>(n) * 28);
+    launch_host_export_hits(c->stream, c->pb, n, d_hits, d_prim);
+    std::vector<float> hits(static_cast<size_t>(n) * 6), b9(static_cast<size_t>(n) * 9);
+    std::vector<uint32_t> prims(n);
+    HIP_TRY(c, hipMemcpyAsync(hits.data(), d_hits, hits.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(prims.data(), d_prim, prims.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    host_parallel_for(n, [&](uint32_t i) {
+        const float* p = &hits[6 * static_cast<size_t>(i)];
+        sc->host_cb.deflect(sc->host_cb.user, prims[i], p, p + 3, &b9[9 * static_cast<size_t>(i)]);
+    });
+    host_totals.host_shades += n;
+    HIP_TRY(c, hipMemcpyAsync(d_b9, b9.data(), b9.size() * 4, hipMemcpyHostToDevice, c->stream));
+    launch_host_apply(c->stream, c->pb, n, d_b9, bounce, max_bounces);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MIPT_OK;
+}
+
 // The bounce loop of one sample batch over the live-path queue of bounce 0.  `first_done` says how far
-// the caller already took bounce 0: 0 = nothing, 1 = closest analytic hit found, 2 = SDF march done too.
+// the caller already took bounce 0: 0 = nothing, 1 = closest analytic hit found, 2 = SDF march done too,
+// 3 = the host-evaluated objects have been asked as well.
 // Leaves per-path radiance in pb.rad (slots that never hit anything keep what the caller put there).
-void enqueue_bounces(mipt_ctx* c, const mipt_scene* sc, const BatchParams& bp, uint32_t bounces, int first_done) {
+// Scenes with host-evaluated objects synchronise the stream twice per bounce; all others only enqueue.
+int enqueue_bounces(mipt_ctx* c, const mipt_scene* sc, const BatchParams& bp, uint32_t bounces, int first_done, Totals* host_totals = nullptr) {
+    Totals local{};
+    Totals& ht = host_totals ? *host_totals : local;
+    const bool host = !sc->host_prims.empty();
     for (uint32_t b = 0; b < bounces; ++b) {
         const int done = b == 0 ? first_done : 0;
         if (b > 0) launch_latch_cancel(c->stream, c->pb);
         if (done < 1) { StageTimer t(c, MIPT_STAGE_EXTEND); launch_extend(c->stream, sc->dev, bp, c->pb, b, sc->depth, c->counting); }
         if (sc->n_sdf && done < 2) { StageTimer t(c, MIPT_STAGE_SDF_MARCH); launch_sdf_march(c->stream, sc->dev, bp, c->pb, b); }
+        if (host && done < 3) {
+            const int rc = host_objects_extend(c, sc, b, ht);
+            if (rc != MIPT_OK) return rc;
+        }
         { StageTimer t(c, MIPT_STAGE_SHADE); launch_shade(c->stream, sc->dev, bp, c->pb, b, bounces); }
         if (sc->n_sdf) { StageTimer t(c, MIPT_STAGE_SHADE_SDF); launch_shade_sdf(c->stream, sc->dev, bp, c->pb, b, bounces); }
+        if (host) {
+            const int rc = host_objects_shade(c, sc, b, bounces, ht);
+            if (rc != MIPT_OK) return rc;
+        }
     }
     // every real path casts a primary ray (tile padding does not)
     const uint32_t primaries = bp.tiles_x ? bp.width * bp.height * (bp.n_slots / bp.n_pix) : bp.n_slots;
     launch_finish_batch(c->stream, c->pb, bounces, primaries);
+    return MIPT_OK;
+}
+
+// PathBuffers::host_queue for scenes with host-evaluated objects: as many entries as the arena has slots.
+int ensure_host_queue(mipt_ctx* c, const mipt_scene* sc) {
+    if (sc->host_prims.empty()) {
+        c->pb.host_queue = c->host_q;
+        return MIPT_OK;
+    }
+    if (c->host_q_cap < c->slots_cap) {
+        if (c->host_q) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipFree(c->host_q));
+            c->host_q = nullptr;
+            c->host_q_cap = 0;
+        }
+        const hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->host_q), c->slots_cap * sizeof(uint32_t));
+        if (e != hipSuccess) {
+            c->last_hip = static_cast<int>(e);
+            return e == hipErrorOutOfMemory ? MIPT_ERR_OUT_OF_MEMORY : MIPT_ERR_HIP;
+        }
+        c->host_q_cap = c->slots_cap;
+    }
+    c->pb.host_queue = c->host_q;
+    return MIPT_OK;
 }
 
 // Image tiles (8 x 8 pixels) that touch one of the cull rectangles, in row-major order; empty = all of them.
@@ -401,6 +585,8 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         (void)hipGetLastError();
         per_batch_max = std::max<size_t>(1, per_batch / 2);
     }
+    if (const int rq = ensure_host_queue(c, sc); rq != MIPT_OK) return rq;
+    Totals host_totals{};
     HIP_TRY(c, hipMemsetAsync(c->pb.totals, 0, sizeof(Totals), c->stream));
     c->ev_used = 0;
     c->spans.clear();
@@ -430,7 +616,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
         launch_latch_cancel(c->stream, c->pb);
         { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate_extend(c->stream, cr, sc->dev, bp, c->pb, cull, sc->depth, c->counting); }
-        enqueue_bounces(c, sc, bp, st->bounces, 1);
+        if (const int rb = enqueue_bounces(c, sc, bp, st->bounces, 1, &host_totals); rb != MIPT_OK) return rb;
         launch_latch_cancel(c->stream, c->pb);
         { StageTimer t(c, MIPT_STAGE_ACCUMULATE); launch_accumulate(c->stream, bp, c->pb, d_sum); }
         HIP_TRY(c, hipEventRecord(c->batch_ev[batch_no & 1], c->stream));
@@ -460,6 +646,8 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         stats->samples_done = t.samples_done;
         stats->node_visits = t.node_visits;
         stats->prim_tests = t.prim_tests;
+        stats->host_rays = host_totals.host_rays;
+        stats->host_shades = host_totals.host_shades;
         stats->ms_device = ms;
         for (int k = 0; k < 6; ++k) {
             stats->stage_ms[k] = 0.0;
@@ -542,6 +730,8 @@ void mipt_shutdown(mipt_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->arena) (void)hipFree(c->arena);
     if (c->vis_tiles) (void)hipFree(c->vis_tiles);
+    if (c->host_q) (void)hipFree(c->host_q);
+    if (c->host_stage) (void)hipFree(c->host_stage);
     for (hipEvent_t e : c->batch_ev)
         if (e) (void)hipEventDestroy(e);
     if (c->frame) (void)hipFree(c->frame);
@@ -569,12 +759,14 @@ int mipt_trim(mipt_ctx* c) {
     std::lock_guard<std::mutex> lock(c->mutex);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (void** p : {&c->arena, reinterpret_cast<void**>(&c->frame), reinterpret_cast<void**>(&c->stage), reinterpret_cast<void**>(&c->vis_tiles)})
+    for (void** p : {&c->arena, reinterpret_cast<void**>(&c->frame), reinterpret_cast<void**>(&c->stage), reinterpret_cast<void**>(&c->vis_tiles),
+                     reinterpret_cast<void**>(&c->host_q), &c->host_stage})
         if (*p) {
             HIP_TRY(c, hipFree(*p));
             *p = nullptr;
         }
-    c->slots_cap = c->bits_cap = c->frame_cap = c->stage_cap = c->vis_cap = 0;
+    c->slots_cap = c->bits_cap = c->frame_cap = c->stage_cap = c->vis_cap = c->host_q_cap = c->host_stage_cap = 0;
+    c->pb.host_queue = nullptr;
     return MIPT_OK;
 }
 
@@ -607,11 +799,14 @@ const char* mipt_strerror(int s) {
 }
 
 int mipt_scene_upload(mipt_ctx* c, const mipt_scene_desc* d, mipt_scene** out) {
-    return mipt_scene_upload_ex(c, d, c && c->device_bvh ? MIPT_UPLOAD_DEVICE_BVH : 0u, out);
+    return mipt_scene_upload_host(c, d, c && c->device_bvh ? MIPT_UPLOAD_DEVICE_BVH : 0u, nullptr, out);
 }
 
-int mipt_scene_upload_ex(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags, mipt_scene** out) {
+int mipt_scene_upload_ex(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags, mipt_scene** out) { return mipt_scene_upload_host(c, d, flags, nullptr, out); }
+
+int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags, const mipt_host_callbacks* cb, mipt_scene** out) {
     if (!c || !d || !out || (flags & ~static_cast<uint32_t>(MIPT_UPLOAD_DEVICE_BVH))) return MIPT_ERR_ARGUMENT;
+    if (cb && (!cb->hit || !cb->deflect)) return MIPT_ERR_ARGUMENT;
     *out = nullptr;
     if (d->n_prims == 0 || !d->kind || !d->fwd || !d->inv || !d->params || !d->material || !d->materials || d->n_materials == 0)
         return MIPT_ERR_ARGUMENT;
@@ -622,15 +817,15 @@ int mipt_scene_upload_ex(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags, 
     std::vector<PrimRec> prims(n);
     std::vector<float> tri_c;
     std::vector<BuildBox> boxes;
-    std::vector<SdfBox> sdf;
+    std::vector<SdfBox> sdf, host_boxes;
     boxes.reserve(n);
     bool any_tri = false, any_sdf = false /* crater balls */, any_plain = false /* SDF kinds evaluated one point per lane */;
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t k = d->kind[i];
-        if (k > MIPT_WEIRDWALL || d->material[i] >= d->n_materials) return MIPT_ERR_ARGUMENT;
+        if (k > MIPT_HOST_OBJECT || (k == MIPT_HOST_OBJECT && !cb) || d->material[i] >= d->n_materials) return MIPT_ERR_ARGUMENT;
         any_tri |= (k == MIPT_TRIANGLE);
         any_sdf |= (k == MIPT_CRATERBALL);
-        any_plain |= (k >= MIPT_ROUGHBOX);
+        any_plain |= (k >= MIPT_ROUGHBOX && k <= MIPT_WEIRDWALL);
     }
     if ((any_sdf || any_plain) && !d->noise_transform) return MIPT_ERR_ARGUMENT;
     if (any_tri) tri_c.assign(static_cast<size_t>(3) * n, 0.0f);
@@ -666,7 +861,13 @@ int mipt_scene_upload_ex(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags, 
             lo[a] -= pad;
             hi[a] += pad;
         }
-        if (r.kind >= MIPT_CRATERBALL) {
+        if (r.kind == MIPT_HOST_OBJECT) {
+            SdfBox s{};
+            std::memcpy(s.lo, lo, sizeof(lo));
+            std::memcpy(s.hi, hi, sizeof(hi));
+            s.prim = i;
+            host_boxes.push_back(s);
+        } else if (r.kind >= MIPT_CRATERBALL) {
             SdfBox s{};
             std::memcpy(s.lo, lo, sizeof(lo));
             std::memcpy(s.hi, hi, sizeof(hi));
@@ -809,6 +1010,7 @@ int mipt_scene_upload_ex(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags, 
     if (e == hipSuccess) e = upload(&s->d_mats, mats.data(), mats.size() * sizeof(MaterialRec));
     if (e == hipSuccess && !d_lbvh) e = upload(&s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode));
     if (e == hipSuccess) e = upload(&s->d_sdf, sdf.data(), sdf.size() * sizeof(SdfBox));
+    if (e == hipSuccess) e = upload(&s->d_host_boxes, host_boxes.data(), host_boxes.size() * sizeof(SdfBox));
     // noise() (PathTracerDemo.cpp:56-70) applies the transform T = (L, t), samples, scales by 1.1 and
     // repeats; octave i therefore samples q_i = A_i p + b_i with A_0 = L, b_0 = t, A_i = 1.1 L A_{i-1},
     // b_i = 1.1 L b_{i-1} + t.  Composed in double, stored as float (13 per octave: A row-major, b + 0.25,
@@ -856,6 +1058,10 @@ int mipt_scene_upload_ex(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags, 
     s->dev.crater_masks = static_cast<const unsigned long long*>(s->d_crater_masks);
     s->dev.n_sdf = static_cast<uint32_t>(sdf.size());
     s->dev.n_prims = n;
+    s->dev.host_boxes = static_cast<const SdfBox*>(s->d_host_boxes);
+    s->dev.n_host = static_cast<uint32_t>(host_boxes.size());
+    for (const SdfBox& hb : host_boxes) s->host_prims.push_back(hb.prim);
+    if (cb) s->host_cb = *cb;
     {
         const float big = std::numeric_limits<float>::max();
         std::array<float, 6> all{big, big, big, -big, -big, -big};
@@ -891,6 +1097,11 @@ int mipt_scene_upload_ex(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags, 
             for (const SdfBox& b : sdf) grow(m, b.lo, b.hi);
             s->cull_boxes.push_back(m);
         }
+        if (!host_boxes.empty()) {   // one box around everything the host evaluates
+            std::array<float, 6> m{big, big, big, -big, -big, -big};
+            for (const SdfBox& b : host_boxes) grow(m, b.lo, b.hi);
+            s->cull_boxes.push_back(m);
+        }
     }
     s->kinds.assign(d->kind, d->kind + n);
     s->n_nodes = n_nodes;
@@ -905,7 +1116,7 @@ void mipt_scene_free(mipt_scene* s) {
     if (!s) return;
     // hipFree waits for work that still uses the memory; the context may already be gone
     (void)hipSetDevice(s->device);
-    for (void* p : {s->d_prims, s->d_tri, s->d_mats, s->d_nodes, s->d_sdf, s->d_oct, s->d_craters, s->d_crater_masks})
+    for (void* p : {s->d_prims, s->d_tri, s->d_mats, s->d_nodes, s->d_sdf, s->d_oct, s->d_craters, s->d_crater_masks, s->d_host_boxes})
         if (p) (void)hipFree(p);
     delete s;
 }
@@ -1049,6 +1260,8 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     if (n > (size_t(1) << 28)) return MIPT_ERR_TOO_LARGE;
     int rc = ensure_slots(c, n, (n + 63) / 64);
     if (rc != MIPT_OK) return rc;
+    rc = ensure_host_queue(c, sc);
+    if (rc != MIPT_OK) return rc;
     c->cancel.store(0);
     *c->cancel_host = 0u;
     BatchParams bp{};
@@ -1064,6 +1277,11 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     launch_latch_cancel(c->stream, c->pb);
     launch_generate_extend(c->stream, pack_camera(c0), sc->dev, bp, c->pb, screen_rects(sc, c0, width, height), sc->depth);
     if (sc->n_sdf) launch_sdf_march(c->stream, sc->dev, bp, c->pb, 0);
+    if (!sc->host_prims.empty()) {
+        Totals unused{};
+        const int rh = host_objects_extend(c, sc, 0, unused);
+        if (rh != MIPT_OK) return rh;
+    }
     std::vector<unsigned long long> keys(n);
     HIP_TRY(c, hipMemcpyAsync(keys.data(), c->pb.hit_key, n * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1090,6 +1308,8 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = ensure_slots(c, n, 1);
     if (rc != MIPT_OK) return rc;
+    rc = ensure_host_queue(c, sc);
+    if (rc != MIPT_OK) return rc;
     c->cancel.store(0);
     *c->cancel_host = 0u;
     rc = ensure_floats(c, &c->stage, &c->stage_cap, static_cast<size_t>(n) * 6);
@@ -1111,10 +1331,17 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
         // first closest hit, before shading overwrites the rays
         launch_extend(c->stream, sc->dev, bp, c->pb, 0, sc->depth);
         if (sc->n_sdf) launch_sdf_march(c->stream, sc->dev, bp, c->pb, 0);
+        if (!sc->host_prims.empty()) {
+            Totals unused{};
+            const int rh = host_objects_extend(c, sc, 0, unused);
+            if (rh != MIPT_OK) return rh;
+        }
         keys.resize(n);
         HIP_TRY(c, hipMemcpyAsync(keys.data(), c->pb.hit_key, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    enqueue_bounces(c, sc, bp, bounces, keys.empty() ? 0 : 2);
+    rc = enqueue_bounces(c, sc, bp, bounces, keys.empty() ? 0 : 3);
+    if (rc != MIPT_OK) return rc;
     launch_export_rad(c->stream, c->pb, n, c->stage);
     HIP_TRY(c, hipMemcpyAsync(out_rgb, c->stage, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -71,6 +71,10 @@ struct SceneDev {
     // the raw noise transform (Linear row-major, then the translation), read by the SDF kinds that run noise() octave by octave
     const float* noise_raw;
     uint32_t plain_sdf;            // the scene holds SDF kinds evaluated one point per lane (RoughBoxObject)
+    // Objects that only the host can evaluate (kind 8: a user's Object subclass behind callbacks): their padded world
+    // boxes.  Rays that reach one are handed to the host between the device stages.
+    const SdfBox* host_boxes;
+    uint32_t n_host;
 };
 
 // Per-bounce queue counters of one sample batch, zeroed once per batch.
@@ -80,7 +84,9 @@ struct BounceCounters {
     uint32_t sdf_head;      // work-fetch cursor of the SDF march
     uint32_t n_sdf_shade;   // hits queued for SDF shading
     uint32_t extend_head[8];   // work-fetch cursors of extend, one per XCD
-    uint32_t pad[4];
+    uint32_t n_host_rays;   // rays gathered for one host object (reset per object)
+    uint32_t n_host_shade;  // hits on host objects queued for shading on the host
+    uint32_t pad[2];
 };
 
 struct Totals {
@@ -89,6 +95,7 @@ struct Totals {
     unsigned long long shade_near_evals, shade_noise_calls;              // shade_sdf: the same for the normals
     unsigned long long primary_traced;                                   // primary rays that were traced rather than culled on screen
     unsigned long long node_visits, prim_tests;                          // counting build of the traversal only
+    unsigned long long host_rays, host_shades;                           // work handed to the host for objects without a device form
     unsigned long long samples_done;                                     // samples per pixel that entered the frame (batches accumulated before a cancel)
 };
 

@@ -84,6 +84,12 @@ bool world_bounds(uint32_t kind, const float fwd[12], const float p[9], float lo
         case 5: h[0] = 2.0f * p[0]; h[1] = 2.0f * p[1]; h[2] = 2.0f * p[2]; break;   // RoughBoxObject::localBoundingBox PathTracerDemo.cpp:261-266
         case 6: h[0] = h[1] = h[2] = 1.2f * p[0]; break;                              // RoughSphereObject::localBoundingBox :216-221
         case 7: h[0] = 50.0f; h[1] = 20.0f; h[2] = 20.0f; break;                      // WeirdWallObject::localBoundingBox :343-348
+        case 8:   // an object evaluated on the host brings its world box along (Object::getBoundingBox: centre, half size)
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = p[k] - p[3 + k];
+                hi[k] = p[k] + p[3 + k];
+            }
+            return true;
         default: return false;
     }
     for (int k = 0; k < 3; ++k) {

@@ -19,6 +19,7 @@ struct PathBuffers {
     uint32_t* queue[2];   // live path slots, ping-pong per bounce
     uint32_t* sdf_queue;  // slots whose ray entered an SDF primitive's box
     uint32_t* sdf_shade_queue;   // slots whose closest hit is an SDF primitive
+    uint32_t* host_queue;        // slots handed to the host (rays that reach a host object's box; hits on host objects); null without host objects
     BounceCounters* counters;    // kMaxBounces + 1 entries
     Totals* totals;
     // one bit per slot, set for the paths whose primary ray hit something or reached an SDF box (only
@@ -72,6 +73,17 @@ void launch_sdf_march(hipStream_t, const SceneDev&, const BatchParams&, const Pa
 void launch_sdf_eval(hipStream_t, const SceneDev&, uint32_t prim, uint32_t lane_threshold, const float* pos3, uint32_t n, float* out);
 void launch_shade(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, uint32_t max_bounces);
 void launch_shade_sdf(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, uint32_t max_bounces);
+// ---- objects evaluated on the host (kind 8) ---------------------------------------------------------------
+// live rays of `bounce` that reach host_boxes[which] before their best hit -> host_queue, counters[bounce].n_host_rays
+void launch_host_gather(hipStream_t, const SceneDev&, const PathBuffers&, uint32_t bounce, uint32_t which);
+// origin and direction (6 floats per entry) of the first n slots of host_queue
+void launch_host_export_rays(hipStream_t, const PathBuffers&, uint32_t n, float* out6);
+// the host's hits: entry i (slot of host_queue[idx[i]]) offers key[i] / pos[i]; the smaller key wins (two launches: keys, then positions)
+void launch_host_merge(hipStream_t, const PathBuffers&, uint32_t n, const uint32_t* idx, const unsigned long long* key, const float* pos3);
+// hit position, incoming direction (6 floats) and primitive of the first n slots of host_queue (hits queued by shade)
+void launch_host_export_hits(hipStream_t, const PathBuffers&, uint32_t n, float* out6, uint32_t* out_prim);
+// applies the host's bounces (9 floats per entry: emitted, attenuation, world direction) to the first n slots of host_queue
+void launch_host_apply(hipStream_t, const PathBuffers&, uint32_t n, const float* bounce9, uint32_t bounce, uint32_t max_bounces);
 void launch_finish_batch(hipStream_t, const PathBuffers&, uint32_t bounces, uint32_t n_slots);
 // frame[pix] += sum over the batch's samples, in sample order (the `acc +=` of src/Renderer.cpp:97-99)
 void launch_latch_cancel(hipStream_t, const PathBuffers&);

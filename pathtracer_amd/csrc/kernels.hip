@@ -544,6 +544,14 @@ __device__ __forceinline__ bool reaches_sdf_box(const SceneDev& sc, f3 lo0, f3 h
     return any;
 }
 
+// Does the ray reach the box of an object that only the host can evaluate, before its best hit?
+__device__ __forceinline__ bool reaches_host_box(const SceneDev& sc, f3 o, f3 inv_d, float limit) {
+    bool any = false;
+    float tn;
+    for (uint32_t k = 0; k < sc.n_host; ++k) any = any || slab(o, inv_d, sc.host_boxes[k].lo, sc.host_boxes[k].hi, limit, tn);
+    return any;
+}
+
 // Adds a per-lane counter into a 64-bit total with one atomic per wave.
 __device__ __forceinline__ void wave_add_total(unsigned long long* total, uint32_t v) {
 #pragma unroll
@@ -720,7 +728,7 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
         bool keep = false, wants_sdf = false;
         if (fin) {
             wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, t.o, t.d, t.inv_d, t.limit, !(bp.flags & kFlagFullMarch));
-            keep = t.best != kMissKey || wants_sdf;
+            keep = t.best != kMissKey || wants_sdf || (sc.n_host && reaches_host_box(sc, t.o, t.inv_d, t.limit));
             if (keep) {
                 pb.ray_o[t.slot] = st4(t.o);
                 pb.ray_d[t.slot] = st4(t.d);
@@ -1123,6 +1131,8 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
     constexpr uint32_t kCap = 1024;
     __shared__ uint32_t s_pend[2 * 4 * kCap];
     PendingQueue survivors{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u}, sdf_hits{s_pend + (4u + (threadIdx.x >> 6)) * kCap, kCap, 0u};
+    __shared__ uint32_t s_host[4 * 128];
+    PendingQueue host_hits{s_host + (threadIdx.x >> 6) * 128u, 128u, 0u};
     const uint32_t n = pb.counters[bounce].n_live;
     const uint32_t* queue = pb.queue[bounce & 1];
     uint32_t* next_queue = pb.queue[(bounce + 1) & 1];
@@ -1131,7 +1141,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
     const uint32_t rounds = (n + stride - 1) / stride;
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        bool alive = false, to_sdf = false;
+        bool alive = false, to_sdf = false, to_host = false;
         uint32_t slot = 0;
         if (i < n) {
             slot = queue[i];
@@ -1140,7 +1150,9 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
                 const uint32_t prim = static_cast<uint32_t>(key & 0xffffffffu);
                 PrimRegs pr;
                 load_prim(sc.prims, prim, pr);
-                if (pr.kind >= 3u) {   // SDF objects: normals need SDF evaluations
+                if (pr.kind == 8u) {   // an object only the host can evaluate: its deflectRay runs there
+                    to_host = true;
+                } else if (pr.kind >= 3u) {   // SDF objects: normals need SDF evaluations
                     to_sdf = true;
                 } else {
                     const f3 wp = ld3(pb.hit_pos[slot]);
@@ -1168,9 +1180,117 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
         }
         pending_push(survivors, alive, slot, &pb.counters[bounce + 1].n_live, next_queue);
         pending_push(sdf_hits, to_sdf, slot, &pb.counters[bounce].n_sdf_shade, pb.sdf_shade_queue);
+        if (sc.n_host) pending_push(host_hits, to_host, slot, &pb.counters[bounce].n_host_shade, pb.host_queue);
     }
     pending_flush(survivors, &pb.counters[bounce + 1].n_live, next_queue);
     pending_flush(sdf_hits, &pb.counters[bounce].n_sdf_shade, pb.sdf_shade_queue);
+    if (sc.n_host) pending_flush(host_hits, &pb.counters[bounce].n_host_shade, pb.host_queue);
+}
+
+// =============================================================================================
+// Objects without a device form (kind 8: a user's Object subclass, include/Object.hpp:45-52).  The device finds
+// the rays that reach such an object's padded world box before their best hit; the host calls the object's hitRay
+// for them, the closer hits are merged by hit key; hits that end up on such an object are shaded by the host's
+// deflectRay and applied here.  Slow by construction (two host round trips per bounce), and exactly the
+// reference's semantics: closest of all objects, ties to the lower index.
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_host_gather(SceneDev sc, PathBuffers pb, uint32_t bounce, uint32_t which) {
+    if (*pb.cancel_latch) return;
+    __shared__ uint32_t s_pend[4 * 512];
+    PendingQueue out{s_pend + (threadIdx.x >> 6) * 512u, 512u, 0u};
+    const uint32_t n = pb.counters[bounce].n_live;
+    const uint32_t* queue = pb.queue[bounce & 1];
+    const SdfBox bx = sc.host_boxes[which];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool reach = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = queue[i];
+            const f3 o = ld3(pb.ray_o[slot]), d = ld3(pb.ray_d[slot]);
+            const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            float limit = 3.0e38f, tn;
+            const unsigned long long best = pb.hit_key[slot];
+            if (best != kMissKey) {
+                const uint32_t ob = static_cast<uint32_t>(best >> 32);
+                const uint32_t fb = (ob & 0x80000000u) ? (ob ^ 0x80000000u) : ~ob;
+                limit = fmaxf(__uint_as_float(fb), 0.0f) * (1.0f / norm_sq(d)) * 1.00001f + 1e-6f;
+            }
+            reach = slab(o, inv_d, bx.lo, bx.hi, limit, tn);
+        }
+        pending_push(out, reach, slot, &pb.counters[bounce].n_host_rays, pb.host_queue);
+    }
+    pending_flush(out, &pb.counters[bounce].n_host_rays, pb.host_queue);
+}
+
+__global__ void __launch_bounds__(256) k_host_export_rays(PathBuffers pb, uint32_t n, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = pb.host_queue[i];
+    const float4 o = pb.ray_o[slot], d = pb.ray_d[slot];
+    float* q = out + 6 * static_cast<size_t>(i);
+    q[0] = o.x; q[1] = o.y; q[2] = o.z; q[3] = d.x; q[4] = d.y; q[5] = d.z;
+}
+
+// pass 0: the smaller key wins; pass 1: the winner's position follows its key
+__global__ void __launch_bounds__(256) k_host_merge(PathBuffers pb, uint32_t n, const uint32_t* idx, const unsigned long long* key, const float* pos, int pass) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = pb.host_queue[idx[i]];
+    if (pass == 0) atomicMin(&pb.hit_key[slot], key[i]);
+    else if (pb.hit_key[slot] == key[i]) pb.hit_pos[slot] = make_float4(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], 0.0f);
+}
+
+__global__ void __launch_bounds__(256) k_host_export_hits(PathBuffers pb, uint32_t n, float* out, uint32_t* out_prim) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = pb.host_queue[i];
+    const float4 p = pb.hit_pos[slot], d = pb.ray_d[slot];
+    float* q = out + 6 * static_cast<size_t>(i);
+    q[0] = p.x; q[1] = p.y; q[2] = p.z; q[3] = d.x; q[4] = d.y; q[5] = d.z;
+    out_prim[i] = static_cast<uint32_t>(pb.hit_key[slot] & 0xffffffffu);
+}
+
+// Scene::trace's per-hit body (src/Scene.cpp:52-75) with the ColorBounce the host's Object::deflectRay returned
+// (its direction is already in world space, src/Object.cpp:42).
+__global__ void __launch_bounds__(256) k_host_apply(PathBuffers pb, uint32_t n, const float* b9, uint32_t bounce, uint32_t max_bounces) {
+    if (*pb.cancel_latch) return;
+    __shared__ uint32_t s_pend[4 * 512];
+    PendingQueue survivors{s_pend + (threadIdx.x >> 6) * 512u, 512u, 0u};
+    uint32_t* next_queue = pb.queue[(bounce + 1) & 1];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool alive = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = pb.host_queue[i];
+            const float* b = b9 + 9 * static_cast<size_t>(i);
+            const f3 wdir = mk3(b[6], b[7], b[8]);
+            const f3 wp = ld3(pb.hit_pos[slot]);
+            const f3 npos = mk3(wp.x + 1e-3f * wdir.x, wp.y + 1e-3f * wdir.y, wp.z + 1e-3f * wdir.z);
+            float4 att = bounce == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : pb.att[slot];
+            float4 rad = bounce == 0 ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : pb.rad[slot];
+            rad.x += b[0] * att.x;
+            rad.y += b[1] * att.y;
+            rad.z += b[2] * att.z;
+            att.x *= b[3];
+            att.y *= b[4];
+            att.z *= b[5];
+            pb.rad[slot] = rad;
+            alive = !(att.x + att.z + att.y < 1e-6f) && (bounce + 1 < max_bounces);
+            if (alive) {
+                pb.att[slot] = att;
+                pb.ray_o[slot] = st4(npos);
+                pb.ray_d[slot] = st4(wdir);
+            }
+        }
+        pending_push(survivors, alive, slot, &pb.counters[bounce + 1].n_live, next_queue);
+    }
+    pending_flush(survivors, &pb.counters[bounce + 1].n_live, next_queue);
 }
 
 // SDF hits: the normal is a forward difference of four SDF evaluations (signedDistanceNormal,
@@ -1550,6 +1670,23 @@ void launch_shade(hipStream_t st, const SceneDev& sc, const BatchParams& bp, con
 void launch_shade_sdf(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, uint32_t max_bounces) {
     if (sc.plain_sdf) hipLaunchKernelGGL(k_shade_sdf_plain, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce, max_bounces);
     else hipLaunchKernelGGL(k_shade_sdf, dim3(256u * 4u), dim3(256), 0, st, sc, bp, pb, bounce, max_bounces);
+}
+
+void launch_host_gather(hipStream_t st, const SceneDev& sc, const PathBuffers& pb, uint32_t bounce, uint32_t which) {
+    hipLaunchKernelGGL(k_host_gather, dim3(256u * 8u), dim3(256), 0, st, sc, pb, bounce, which);
+}
+void launch_host_export_rays(hipStream_t st, const PathBuffers& pb, uint32_t n, float* out6) {
+    hipLaunchKernelGGL(k_host_export_rays, dim3((n + 255) / 256), dim3(256), 0, st, pb, n, out6);
+}
+void launch_host_merge(hipStream_t st, const PathBuffers& pb, uint32_t n, const uint32_t* idx, const unsigned long long* key, const float* pos3) {
+    hipLaunchKernelGGL(k_host_merge, dim3((n + 255) / 256), dim3(256), 0, st, pb, n, idx, key, pos3, 0);
+    hipLaunchKernelGGL(k_host_merge, dim3((n + 255) / 256), dim3(256), 0, st, pb, n, idx, key, pos3, 1);
+}
+void launch_host_export_hits(hipStream_t st, const PathBuffers& pb, uint32_t n, float* out6, uint32_t* out_prim) {
+    hipLaunchKernelGGL(k_host_export_hits, dim3((n + 255) / 256), dim3(256), 0, st, pb, n, out6, out_prim);
+}
+void launch_host_apply(hipStream_t st, const PathBuffers& pb, uint32_t n, const float* bounce9, uint32_t bounce, uint32_t max_bounces) {
+    hipLaunchKernelGGL(k_host_apply, dim3(grid_for(n, 256u * 8u)), dim3(256), 0, st, pb, n, bounce9, bounce, max_bounces);
 }
 
 void launch_finish_batch(hipStream_t st, const PathBuffers& pb, uint32_t bounces, uint32_t n_slots) {

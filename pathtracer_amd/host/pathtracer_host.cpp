@@ -653,6 +653,9 @@ struct SceneDeviceState {
     std::vector<uint32_t> kind, material;
     std::vector<float> fwd, inv, params, materials;
     float noise[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    // objects without a device form, by primitive index (null for device primitives): evaluated through their own
+    // virtuals by the callbacks below
+    std::vector<const Object*> host_objects;
     ~SceneDeviceState() {
         if (scene) mipt_scene_free(scene);
     }
@@ -683,6 +686,27 @@ struct RendererState {
     }
 };
 
+// The callbacks of mipt_scene_upload_host for objects the device does not know: the object's own non-virtual wrappers
+// (src/Object.cpp:22-44), which call the user's hitLocalRay / deflectLocalRay.  Called from the library's worker threads.
+namespace {
+int host_object_hit(void* user, uint32_t prim, const float pos[3], const float dir[3], float out[3]) {
+    const auto* st = static_cast<const SceneDeviceState*>(user);
+    const auto hit = st->host_objects[prim]->hitRay(Ray(Vec(dir[0], dir[1], dir[2]), Pos(pos[0], pos[1], pos[2])));
+    if (!hit) return 0;
+    out[0] = hit->x;
+    out[1] = hit->y;
+    out[2] = hit->z;
+    return 1;
+}
+void host_object_deflect(void* user, uint32_t prim, const float pos[3], const float dir[3], float out9[9]) {
+    const auto* st = static_cast<const SceneDeviceState*>(user);
+    const ColorBounce b = st->host_objects[prim]->deflectRay(Ray(Vec(dir[0], dir[1], dir[2]), Pos(pos[0], pos[1], pos[2])));
+    out9[0] = b.emitted.r; out9[1] = b.emitted.g; out9[2] = b.emitted.b;
+    out9[3] = b.attenuation.r; out9[4] = b.attenuation.g; out9[5] = b.attenuation.b;
+    out9[6] = b.rayDirection.x; out9[7] = b.rayDirection.y; out9[8] = b.rayDirection.z;
+}
+}   // namespace
+
 // Flattens the objects (Scene::updateGeometry's job in this design) and uploads when anything changed.
 // The caller holds the scene's device-state lock until it has finished rendering from the returned scene.
 mipt_scene* sync_scene(const Scene& scene) {
@@ -694,15 +718,23 @@ mipt_scene* sync_scene(const Scene& scene) {
     std::vector<float> fwd(12 * n), inv(12 * n), params(9 * n), materials(14 * n);
     bool any_sdf = false;
     const float* own_noise = nullptr;
+    std::vector<const Object*> host_objects(n, nullptr);
+    bool any_host = false;
+    static const BasicMaterial unused_material;   // the material row of a host-evaluated object is never read
     for (std::size_t i = 0; i < n; ++i) {
         DevicePrimitive d;
         objs[i]->describeForDevice(d);
         if (d.kind < 0 || !d.material) {
-            std::fprintf(stderr,
-                         "pathtracer: object %zu (type %s) has no device counterpart: supported are SphereObject, BoxObject, TriangleObject, FractalObject, the demo's "
-                         "CraterBallObject, RoughBoxObject, RoughSphereObject and WeirdWallObject, and SDF classes that specialise mipt_host::DeviceSdf.\n",
-                         i, d.type_name);
-            std::abort();
+            // Any other Object subclass (the reference lets a user override hitLocalRay / deflectLocalRay / getLocalBoundingBox,
+            // include/Object.hpp:45-52): no device form -- rays that reach its world box are evaluated by the object's own
+            // virtuals on host threads, between the device stages (the slow path; said once per scene upload).
+            d.kind = MIPT_HOST_OBJECT;
+            d.material = &unused_material;
+            const AxisAlignedBox box = objs[i]->getBoundingBox();
+            const float p[9] = {box.center.x, box.center.y, box.center.z, box.halfSize.x, box.halfSize.y, box.halfSize.z, 0.0f, 0.0f, 0.0f};
+            std::memcpy(d.params, p, sizeof(p));
+            host_objects[i] = objs[i].get();
+            any_host = true;
         }
         kind[i] = static_cast<uint32_t>(d.kind);
         any_sdf |= d.kind == MIPT_CRATERBALL || d.kind >= MIPT_ROUGHBOX;
@@ -724,7 +756,7 @@ mipt_scene* sync_scene(const Scene& scene) {
         affine_to(noiseTransform(), noise);
     }
     const bool same = st.scene && kind == st.kind && material == st.material && fwd == st.fwd && inv == st.inv && params == st.params &&
-                      materials == st.materials && std::memcmp(noise, st.noise, sizeof(noise)) == 0;
+                      materials == st.materials && std::memcmp(noise, st.noise, sizeof(noise)) == 0 && host_objects == st.host_objects;
     if (same) return st.scene;
     if (st.scene) {
         mipt_scene_free(st.scene);
@@ -740,7 +772,19 @@ mipt_scene* sync_scene(const Scene& scene) {
     desc.n_materials = static_cast<uint32_t>(n);
     desc.materials = materials.data();
     desc.noise_transform = noise;
-    const int rc = mipt_scene_upload(shared_context(), &desc, &st.scene);
+    st.host_objects = std::move(host_objects);
+    int rc;
+    if (any_host) {
+        std::size_t count = 0;
+        for (const Object* o : st.host_objects) count += o ? 1 : 0;
+        std::fprintf(stderr, "pathtracer: %zu object(s) of this scene have no device form (first: %s); their rays are evaluated by their own virtuals on the "
+                             "host between the GPU stages -- the slow path\n", count, typeid(**std::find_if(st.host_objects.begin(), st.host_objects.end(), [](const Object* o) { return o != nullptr; })).name());
+        const mipt_host_callbacks cb{host_object_hit, host_object_deflect, &st};
+        rc = mipt_scene_upload_host(shared_context(), &desc, std::getenv("MIPT_DEVICE_BVH") && std::atoi(std::getenv("MIPT_DEVICE_BVH")) ? static_cast<uint32_t>(MIPT_UPLOAD_DEVICE_BVH) : 0u, &cb,
+                                    &st.scene);
+    } else {
+        rc = mipt_scene_upload(shared_context(), &desc, &st.scene);
+    }
     if (rc != MIPT_OK) fail("mipt_scene_upload", rc);
     st.kind = std::move(kind);
     st.material = std::move(material);

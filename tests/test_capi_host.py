@@ -97,7 +97,7 @@ def test_no_entry_point_takes_the_context_lock_twice():
         bodies[m.group(1)] = src[m.end():i]
     assert len(bodies) >= 20
     locking = {name for name, body in bodies.items() if "lock_guard" in body}
-    assert {"mipt_render", "mipt_tonemap", "mipt_tonemap_device", "mipt_scene_upload_ex"} <= locking
+    assert {"mipt_render", "mipt_tonemap", "mipt_tonemap_device", "mipt_scene_upload_host"} <= locking
     for name in locking:
         called = set(re.findall(r"\b(mipt_\w+)\s*\(", bodies[name])) & locking
         assert not called, f"{name} holds the context lock and calls {sorted(called)}"

@@ -286,7 +286,7 @@ def test_upload_and_render_refuse_bad_input(ctx, alg, oracle):
     import dataclasses
     good = S.cornell_scene(alg)
     bad_kind = dataclasses.replace(good, kind=good.kind.copy())
-    bad_kind.kind[1] = 8                                            # no such Object subclass
+    bad_kind.kind[1] = 9                                            # no such Object subclass
     bad_material = dataclasses.replace(good, material=good.material.copy())
     bad_material.material[0] = good.materials.shape[0]              # index past the material table
     singular = dataclasses.replace(good, fwd=good.fwd.copy())
