@@ -216,6 +216,9 @@ int  mipt_render_accumulate(mipt_ctx*, const mipt_scene*, const mipt_camera*, co
 /* device_out[i] = device_in[i] * k  (the `acc * sppInv` of src/Renderer.cpp:102-105); in-place allowed. */
 int  mipt_scale_device(mipt_ctx*, const float* device_in, float k, size_t n_floats, float* device_out);
 
+/* device_dst[i] += device_src[i] (the `acc += rendered` of PathTracerDemo.cpp:963-964 for buffers on one device). */
+int  mipt_add_device(mipt_ctx*, float* device_dst, const float* device_src, size_t n_floats);
+
 /* Device buffers of floats for hosts without a HIP toolchain of their own (the C++ host library builds with plain
  * g++): the accumulator of a progressive display loop.  No counterpart in the reference, whose accumulator is a host
  * Image (PathTracerDemo.cpp:934-968).  alloc returns n zero-filled floats; read copies p[i] * k to host memory. */
@@ -248,6 +251,32 @@ int  mipt_trace_rays(mipt_ctx*, const mipt_scene*, uint32_t n, const float* ray_
  * FractalObject::signedDistance (src/Object.cpp:198-252), RoughBoxObject (:237-246), RoughSphereObject (:165-182),
  * WeirdWallObject (:281-328).  pos3 = n x 3 floats, out = n floats (host). */
 int  mipt_sdf_eval(mipt_ctx*, const mipt_scene*, uint32_t prim, uint32_t n, const float* pos3, float* out);
+
+/* ---- one process, several GPUs -------------------------------------------------------------------------
+ * Renderer::render (src/Renderer.cpp:139-172) across the GPUs of a node, where the reference spreads 8-pixel tasks
+ * over CPU threads (src/Renderer.cpp:54-137): the frame's samples per pixel are divided into one contiguous block per
+ * device (random numbers are keyed by the global sample index, so the set of samples does not depend on the number
+ * of devices), every device adds its block into a full-frame radiance-sum buffer of its own, ONE RCCL all-reduce
+ * (ncclAllReduce, sum, f32, width*height*3 elements) over xGMI combines them, and the first device scales by
+ * 1 / spp, tone-maps and copies the frame to the host.  RCCL is loaded when mipt_init_all is called (librccl.so.1), not
+ * before.
+ *   mipt_init_all(n, devices, flags, out): devices = NULL -> devices 0 .. n-1 (n = 0: all of the node's).
+ *   MIPT_NODE_SIMULATE: no RCCL; `devices` may then name one device several times, every entry being one shard with a
+ *   context of its own, and the shards' buffers are added on that device -- what k GPUs compute, on one (for tests).
+ * One process per GPU with the caller's own collective (mipt_render_accumulate, above) remains the other way. */
+typedef struct mipt_node mipt_node;
+typedef struct mipt_node_scene mipt_node_scene;
+enum { MIPT_NODE_SIMULATE = 1u };
+int  mipt_init_all(int n_devices, const int* devices, uint32_t flags, mipt_node** out);
+void mipt_node_shutdown(mipt_node*);
+int  mipt_node_size(const mipt_node*);
+mipt_ctx* mipt_node_ctx(mipt_node*, int shard);
+int  mipt_node_cancel(mipt_node*);                                   /* Renderer::cancelRender for every shard */
+int  mipt_node_scene_upload(mipt_node*, const mipt_scene_desc*, mipt_node_scene** out);   /* Scene::updateGeometry on every device */
+void mipt_node_scene_free(mipt_node*, mipt_node_scene*);
+/* tonemap: -1 none, 0 Reinhard, 1 filmic (src/ToneMapper.cpp), applied on the GPU after the all-reduce */
+int  mipt_node_render(mipt_node*, const mipt_node_scene*, const mipt_camera*, const mipt_settings*, int tonemap, float* out_rgb,
+                      mipt_stats* stats /* nullable; summed over the shards */);
 
 /* ---- tone mapping ------------------------------------------------------------------------- */
 /* ReinhardToneMapper / FilmicToneMapper::operator() (src/ToneMapper.cpp:6-72): kind 0 Reinhard,

@@ -229,3 +229,57 @@ class Context:
     def tonemap_device(self, kind, in_ptr, out_ptr, w, h):
         check(capi.dll().mipt_tonemap_device(self.h, kind, C.c_void_p(in_ptr), C.c_void_p(out_ptr), w, h),
               "mipt_tonemap_device")
+
+
+NODE_SIMULATE = 1
+
+
+class Node:
+    """Several GPUs driven by one process (mipt_init_all): samples sharded over the devices, one RCCL all-reduce per frame.
+    devices=None: the first n devices (n = 0: all).  simulate=True: no RCCL, entries of `devices` may repeat (k shards on one GPU)."""
+
+    def __init__(self, n=0, devices=None, simulate=False):
+        h = C.c_void_p()
+        arr = None
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            n = len(devices)
+        check(capi.dll().mipt_init_all(n, arr, NODE_SIMULATE if simulate else 0, C.byref(h)), "mipt_init_all")
+        self.h = h
+        self._scenes = []
+
+    def size(self):
+        return int(capi.dll().mipt_node_size(self.h))
+
+    def upload(self, flat):
+        keep = [np.ascontiguousarray(flat.kind, np.uint32), f32(flat.fwd), f32(flat.inv), f32(flat.params),
+                np.ascontiguousarray(flat.material, np.uint32), f32(flat.materials), f32(flat.noise)]
+        k, fwd, inv, par, mat, mats, noise = keep
+        d = capi.SceneDesc(k.shape[0], k.ctypes.data_as(capi._u32p), fp(fwd), fp(inv), fp(par),
+                           mat.ctypes.data_as(capi._u32p), mats.shape[0], fp(mats), fp(noise))
+        s = C.c_void_p()
+        check(capi.dll().mipt_node_scene_upload(self.h, C.byref(d), C.byref(s)), "mipt_node_scene_upload")
+        self._scenes.append(s)
+        return s
+
+    def render(self, scene, cam16, w, h, bounces, spp, seed=1, tonemap=-1, first_sample=0):
+        cam = capi.make_camera(cam16)
+        st = capi.Settings(w, h, bounces, spp, seed, first_sample, 0)
+        out = np.zeros((h, w, 3), np.float32)
+        stats = capi.Stats()
+        check(capi.dll().mipt_node_render(self.h, scene, C.byref(cam), C.byref(st), int(tonemap), fp(out), C.byref(stats)), "mipt_node_render")
+        return out, Context._stats(stats)
+
+    def close(self):
+        if self.h:
+            for s in self._scenes:
+                capi.dll().mipt_node_scene_free(self.h, s)
+            self._scenes = []
+            capi.dll().mipt_node_shutdown(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass

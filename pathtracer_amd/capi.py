@@ -64,7 +64,8 @@ EXPORTS = [
     "mipt_scene_free", "mipt_scene_info", "mipt_render", "mipt_render_accumulate", "mipt_scale_device",
     "mipt_primary_hits", "mipt_trace_rays", "mipt_tonemap", "mipt_tonemap_device", "mipt_affine_inverse",
     "mipt_rotation", "mipt_affine_mul", "mipt_noise_transform", "mipt_world_bounds", "mipt_present_rgba8",
-    "mipt_tonemap_device_noalloc", "mipt_trim", "mipt_sdf_eval", "mipt_set_counting", "mipt_device_floats_write", "mipt_scene_upload_host",
+    "mipt_tonemap_device_noalloc", "mipt_trim", "mipt_sdf_eval", "mipt_set_counting", "mipt_device_floats_write", "mipt_scene_upload_host", "mipt_add_device", "mipt_init_all", "mipt_node_shutdown", "mipt_node_size", "mipt_node_ctx",
+    "mipt_node_cancel", "mipt_node_scene_upload", "mipt_node_scene_free", "mipt_node_render",
 ]
 
 _dll = None
@@ -89,6 +90,18 @@ def dll():
         d.mipt_scene_upload.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         d.mipt_scene_upload_ex.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.c_uint32, C.POINTER(C.c_void_p)]
         d.mipt_scene_upload_host.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.c_uint32, C.POINTER(HostCallbacks), C.POINTER(C.c_void_p)]
+        d.mipt_add_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        d.mipt_init_all.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_uint32, C.POINTER(C.c_void_p)]
+        d.mipt_node_shutdown.argtypes = [C.c_void_p]
+        d.mipt_node_shutdown.restype = None
+        d.mipt_node_size.argtypes = [C.c_void_p]
+        d.mipt_node_ctx.argtypes = [C.c_void_p, C.c_int]
+        d.mipt_node_ctx.restype = C.c_void_p
+        d.mipt_node_cancel.argtypes = [C.c_void_p]
+        d.mipt_node_scene_upload.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+        d.mipt_node_scene_free.argtypes = [C.c_void_p, C.c_void_p]
+        d.mipt_node_scene_free.restype = None
+        d.mipt_node_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Camera), C.POINTER(Settings), C.c_int, _f32p, C.POINTER(Stats)]
         d.mipt_device_floats_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         d.mipt_device_floats_zero.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         d.mipt_device_floats_read.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_size_t, _f32p]

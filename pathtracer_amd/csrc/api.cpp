@@ -1164,6 +1164,15 @@ int mipt_scale_device(mipt_ctx* c, const float* in, float k, size_t n, float* ou
     return MIPT_OK;
 }
 
+int mipt_add_device(mipt_ctx* c, float* dst, const float* src, size_t n) {
+    if (!c || !dst || !src) return MIPT_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    HIP_TRY(c, hipSetDevice(c->device));
+    launch_add(c->stream, dst, src, n);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MIPT_OK;
+}
+
 int mipt_device_floats_alloc(mipt_ctx* c, size_t n, float** out) {
     if (!c || !out || n == 0) return MIPT_ERR_ARGUMENT;
     *out = nullptr;

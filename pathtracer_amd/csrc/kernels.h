@@ -89,6 +89,7 @@ void launch_finish_batch(hipStream_t, const PathBuffers&, uint32_t bounces, uint
 void launch_latch_cancel(hipStream_t, const PathBuffers&);
 void launch_accumulate(hipStream_t, const BatchParams&, const PathBuffers&, float* frame_sum);
 void launch_scale(hipStream_t, const float* in, float k, size_t n, float* out);
+void launch_add(hipStream_t, float* dst, const float* src, size_t n);   // dst[i] += src[i]
 void launch_pack_rgba8(hipStream_t, const float* in_rgb, size_t n_pix, uint32_t* out_rgba);
 void launch_load_rays(hipStream_t, const float* pos3, const float* dir3, uint32_t n, const PathBuffers&);
 void launch_export_rad(hipStream_t, const PathBuffers&, uint32_t n, float* out3);

@@ -1486,6 +1486,11 @@ __global__ void __launch_bounds__(256) k_scale(const float* in, float k, size_t 
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i] * k;
 }
 
+__global__ void __launch_bounds__(256) k_add(float* dst, const float* src, size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
+}
+
 // copyToSFImage's conversion (PathTracerDemo.cpp:524-545): clamp to [0, 1], times 255, truncate; bytes R, G, B, A = 255
 __global__ void __launch_bounds__(256) k_pack_rgba8(const float* in, size_t n_pix, uint32_t* out) {
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
@@ -1701,6 +1706,10 @@ void launch_accumulate(hipStream_t st, const BatchParams& bp, const PathBuffers&
 
 void launch_scale(hipStream_t st, const float* in, float k, size_t n, float* out) {
     hipLaunchKernelGGL(k_scale, dim3(grid_for(n)), dim3(256), 0, st, in, k, n, out);
+}
+
+void launch_add(hipStream_t st, float* dst, const float* src, size_t n) {
+    hipLaunchKernelGGL(k_add, dim3(grid_for(n)), dim3(256), 0, st, dst, src, n);
 }
 
 void launch_pack_rgba8(hipStream_t st, const float* in, size_t n_pix, uint32_t* out) {

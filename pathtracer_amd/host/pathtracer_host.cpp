@@ -650,6 +650,9 @@ struct SceneDeviceState {
     // (src/Renderer.cpp:139-172); here a render refreshes the device copy first, so renders of one scene are serialised.
     std::mutex mutex;
     mipt_scene* scene = nullptr;
+    // when the renderer drives several GPUs (MIPT_GPUS): the scene on every device of that renderer's node
+    mipt_node* node = nullptr;
+    mipt_node_scene* node_scene = nullptr;
     std::vector<uint32_t> kind, material;
     std::vector<float> fwd, inv, params, materials;
     float noise[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
@@ -658,6 +661,7 @@ struct SceneDeviceState {
     std::vector<const Object*> host_objects;
     ~SceneDeviceState() {
         if (scene) mipt_scene_free(scene);
+        if (node_scene) mipt_node_scene_free(node, node_scene);
     }
 };
 
@@ -670,6 +674,25 @@ struct RendererState {
     // cancelRender() stops this renderer's frame and no other's; scenes and tone mappers use the shared context of
     // the same device.
     std::atomic<mipt_ctx*> ctx{nullptr};
+    // MIPT_GPUS = N (or "all"): this renderer divides every frame's samples among N GPUs of the node and combines
+    // them with one RCCL all-reduce (mipt_init_all); unset or 1: the single device MIPT_DEVICE names.
+    std::atomic<mipt_node*> node{nullptr};
+    bool node_tried = false;
+    mipt_node* gpus() {   // caller holds `mutex`
+        if (!node_tried) {
+            node_tried = true;
+            if (const char* e = std::getenv("MIPT_GPUS")) {
+                const int n = std::strcmp(e, "all") == 0 ? 0 : std::atoi(e);
+                if (n == 0 || n > 1) {
+                    mipt_node* nd = nullptr;
+                    const int rc = mipt_init_all(n, nullptr, 0, &nd);
+                    if (rc != MIPT_OK) fail("mipt_init_all (MIPT_GPUS)", rc);
+                    node.store(nd, std::memory_order_release);
+                }
+            }
+        }
+        return node.load(std::memory_order_acquire);
+    }
     mipt_ctx* context() {   // caller holds `mutex`
         mipt_ctx* c = ctx.load(std::memory_order_acquire);
         if (!c) {
@@ -683,6 +706,7 @@ struct RendererState {
     }
     ~RendererState() {
         if (mipt_ctx* c = ctx.load()) mipt_shutdown(c);
+        if (mipt_node* nd = node.load()) mipt_node_shutdown(nd);
     }
 };
 
@@ -709,7 +733,7 @@ void host_object_deflect(void* user, uint32_t prim, const float pos[3], const fl
 
 // Flattens the objects (Scene::updateGeometry's job in this design) and uploads when anything changed.
 // The caller holds the scene's device-state lock until it has finished rendering from the returned scene.
-mipt_scene* sync_scene(const Scene& scene) {
+mipt_scene* sync_scene(const Scene& scene, mipt_node* node = nullptr) {
     SceneDeviceState& st = scene.deviceState();
     const auto& objs = scene.objects();
     const std::size_t n = objs.size();
@@ -755,12 +779,17 @@ mipt_scene* sync_scene(const Scene& scene) {
         }
         affine_to(noiseTransform(), noise);
     }
-    const bool same = st.scene && kind == st.kind && material == st.material && fwd == st.fwd && inv == st.inv && params == st.params &&
+    const bool uploaded = node ? (st.node_scene && st.node == node) : st.scene != nullptr;
+    const bool same = uploaded && kind == st.kind && material == st.material && fwd == st.fwd && inv == st.inv && params == st.params &&
                       materials == st.materials && std::memcmp(noise, st.noise, sizeof(noise)) == 0 && host_objects == st.host_objects;
     if (same) return st.scene;
     if (st.scene) {
         mipt_scene_free(st.scene);
         st.scene = nullptr;
+    }
+    if (st.node_scene) {
+        mipt_node_scene_free(st.node, st.node_scene);
+        st.node_scene = nullptr;
     }
     mipt_scene_desc desc{};
     desc.n_prims = static_cast<uint32_t>(n);
@@ -774,7 +803,11 @@ mipt_scene* sync_scene(const Scene& scene) {
     desc.noise_transform = noise;
     st.host_objects = std::move(host_objects);
     int rc;
-    if (any_host) {
+    if (node) {
+        if (any_host) fail("Renderer::render on several GPUs (MIPT_GPUS): the scene holds an object without a device form, which only the single-GPU path evaluates", MIPT_ERR_ARGUMENT);
+        st.node = node;
+        rc = mipt_node_scene_upload(node, &desc, &st.node_scene);
+    } else if (any_host) {
         std::size_t count = 0;
         for (const Object* o : st.host_objects) count += o ? 1 : 0;
         std::fprintf(stderr, "pathtracer: %zu object(s) of this scene have no device form (first: %s); their rays are evaluated by their own virtuals on the "
@@ -933,8 +966,17 @@ mipt_settings next_frame_settings(mipt_host::RendererState& rs, const RenderSett
 
 Image Renderer::render(const Scene& scene, const Camera& camera, const RenderSettings& settings) {
     std::lock_guard<std::mutex> lock(m_state->mutex);
-    mipt_ctx* ctx = m_state->context();
     std::lock_guard<std::mutex> scene_lock(scene.deviceState().mutex);
+    if (mipt_node* node = m_state->gpus()) {   // the samples divided among the node's GPUs, one all-reduce
+        mipt_host::sync_scene(scene, node);
+        const mipt_camera cam = pack_camera(camera);
+        const mipt_settings st = next_frame_settings(*m_state, settings);
+        Image img(settings.width(), settings.height());
+        const int rc = mipt_node_render(node, scene.deviceState().node_scene, &cam, &st, -1, img.raw(), nullptr);
+        if (rc != MIPT_OK && rc != MIPT_ERR_CANCELLED) mipt_host::fail("mipt_node_render", rc);
+        return img;
+    }
+    mipt_ctx* ctx = m_state->context();
     mipt_scene* dev = mipt_host::sync_scene(scene);
     const mipt_camera cam = pack_camera(camera);
     const mipt_settings st = next_frame_settings(*m_state, settings);
@@ -946,6 +988,7 @@ Image Renderer::render(const Scene& scene, const Camera& camera, const RenderSet
 
 void Renderer::cancelRender() noexcept {   // any thread, lock-free (src/Renderer.cpp:174-176)
     if (mipt_ctx* c = m_state->ctx.load(std::memory_order_acquire)) mipt_cancel(c);
+    if (mipt_node* nd = m_state->node.load(std::memory_order_acquire)) mipt_node_cancel(nd);
 }
 
 void Renderer::setSeed(std::uint64_t seed) noexcept {

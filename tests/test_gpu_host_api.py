@@ -133,3 +133,22 @@ def test_progressive_frame_resumes_from_a_checkpoint(ctx, tmp_path):
     assert np.allclose(sums, half * 6.0, rtol=1e-6, atol=1e-7)
     tail = np.fromfile(str(out) + ".ckpt", np.uint64, offset=16 + 96 * 64 * 12)
     assert tail.shape == (5,) and tail[1] == 6 and tail[2] == 2 and tail[3] == 9 and tail[4] == 2
+
+
+def test_renderer_over_the_nodes_gpus_equals_the_single_gpu_frame(tmp_path):
+    """MIPT_GPUS=all: Renderer::render divides the frame's samples among every GPU of the node and combines them with one
+    RCCL all-reduce (mipt_init_all / mipt_node_render).  On this one-GPU box that is a node of one rank, and the frame
+    is the single-GPU frame bit for bit."""
+    exe = os.path.join(LIB, "demo_headless")
+    if not os.path.exists(exe):
+        pytest.skip("demo_headless not built (make -C pathtracer_amd/host example)")
+    outs = []
+    for gpus in (None, "all"):
+        out = tmp_path / f"frame_{gpus}.img"
+        env = {k: v for k, v in os.environ.items() if k != "MIPT_GPUS"}
+        if gpus:
+            env["MIPT_GPUS"] = gpus
+        r = subprocess.run([exe, "96", "64", "8", "8", "11", str(out)], capture_output=True, text=True, timeout=100, env=env)
+        assert r.returncode == 0, r.stderr
+        outs.append(_load_image(out))
+    assert np.array_equal(outs[0], outs[1]) and outs[0].max() > 0
