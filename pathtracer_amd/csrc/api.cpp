@@ -55,6 +55,7 @@ struct mipt_ctx {
     bool device_bvh = false;        // MIPT_DEVICE_BVH=1: mipt_scene_upload builds the tree on the GPU
     bool full_march = false;        // MIPT_FULL_MARCH=1: no shortcut for SDF marches that cannot end (for the equivalence test)
     uint32_t lane_threshold = 14;   // MIPT_LANE_THRESHOLD: 1 = always one point per lane, 65 = never
+    uint32_t trav_quorum = 20, trav_keep = 48;   // MIPT_LEAF_QUORUM, MIPT_KEEP_BUSY: scheduling of the BVH traversal's two phases (tuning aids)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // optional per-launch timing
@@ -612,6 +613,8 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.first_sample = st->first_sample + done;
         bp.flags = (st->flags & static_cast<uint32_t>(MIPT_FLAG_NO_JITTER)) | (c->full_march ? kFlagFullMarch : 0u);
         bp.lane_threshold = c->lane_threshold;
+    bp.trav_quorum = c->trav_quorum;
+    bp.trav_keep = c->trav_keep;
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
         launch_latch_cancel(c->stream, c->pb);
@@ -716,6 +719,8 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
     }
     if (const char* e = std::getenv("MIPT_FULL_MARCH")) c->full_march = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_DEVICE_BVH")) c->device_bvh = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_LEAF_QUORUM")) c->trav_quorum = static_cast<uint32_t>(std::min(64L, std::max(1L, std::atol(e))));
+    if (const char* e = std::getenv("MIPT_KEEP_BUSY")) c->trav_keep = static_cast<uint32_t>(std::min(64L, std::max(0L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_LANE_THRESHOLD")) {
         const long v = std::atol(e);
         if (v >= 1 && v <= 65) c->lane_threshold = static_cast<uint32_t>(v);
@@ -1279,6 +1284,8 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     bp.height = height;
     bp.flags = MIPT_FLAG_NO_JITTER | (c->full_march ? kFlagFullMarch : 0u);
     bp.lane_threshold = c->lane_threshold;
+    bp.trav_quorum = c->trav_quorum;
+    bp.trav_keep = c->trav_keep;
     mipt_camera c0 = *cam;
     c0.blur_radius = 0.0f;
     HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
@@ -1330,6 +1337,8 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     bp.width = n;
     bp.height = 1;
     bp.lane_threshold = c->lane_threshold;
+    bp.trav_quorum = c->trav_quorum;
+    bp.trav_keep = c->trav_keep;
     bp.flags = c->full_march ? kFlagFullMarch : 0u;
     bp.seed = seed;
     HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));

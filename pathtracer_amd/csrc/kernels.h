@@ -49,6 +49,8 @@ struct BatchParams {
     uint32_t first_sample;  // global sample index of sample 0 of this batch
     uint32_t flags;
     uint32_t lane_threshold;   // SDF near field: waiting lanes from which a wave evaluates one point per lane
+    uint32_t trav_quorum;      // BVH traversal: lanes with a pending leaf from which a wave runs a leaf step (20)
+    uint32_t trav_keep;        // BVH traversal: a wave refills its idle lanes when fewer than trav_keep / 64 of its busy lanes are unfinished (48)
     uint64_t seed;
 };
 

@@ -498,8 +498,8 @@ struct TravCounts {
     uint32_t nodes, prims;
 };
 template <bool COUNT>
-__device__ __forceinline__ void trav_run(const SceneDev& sc, Trav& t, int* stack, uint32_t keep_busy, TravCounts& counts) {
-    constexpr uint32_t kLeafQuorum = 20;   // lanes with a pending leaf that make a leaf step worth its cost
+__device__ __forceinline__ void trav_run(const SceneDev& sc, Trav& t, int* stack, uint32_t keep_busy, TravCounts& counts, uint32_t kLeafQuorum = 20u) {
+    // kLeafQuorum: lanes with a pending leaf that make a leaf step worth its cost
     for (;;) {
         if (trav_wants_inner(t)) {
             trav_inner_step(sc, t, stack);
@@ -722,7 +722,7 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
         // The wave's 64 rays of one sample run to the end together: neighbouring pixels take about equally
         // long, and their queue entries then name 64 consecutive slots, which is what lets the kernels that
         // read the queue later fetch the paths' state in full cache lines.
-        trav_run<COUNT>(sc, t, stack, 0u, counts);
+        trav_run<COUNT>(sc, t, stack, 0u, counts, bp.trav_quorum);
         // finished rays: keep what hit something or reaches an SDF box
         const bool fin = trav_finished(t);
         bool keep = false, wants_sdf = false;
@@ -800,7 +800,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
             continue;
         }
         const uint32_t n_busy = static_cast<uint32_t>(__popcll(__ballot(t.busy)));
-        trav_run<COUNT>(sc, t, stack, xcd_cursor_empty(cursor) ? 0u : (3u * n_busy) / 4u, counts);
+        trav_run<COUNT>(sc, t, stack, xcd_cursor_empty(cursor) ? 0u : (bp.trav_keep * n_busy) / 64u, counts, bp.trav_quorum);
         const bool fin = trav_finished(t);
         bool wants_sdf = false;
         if (fin) {
