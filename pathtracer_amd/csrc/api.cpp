@@ -74,12 +74,14 @@ struct mipt_scene {
     void* d_tri = nullptr;
     void* d_mats = nullptr;
     void* d_nodes = nullptr;
+    void* d_leaf_boxes = nullptr;
     void* d_sdf = nullptr;
     void* d_oct = nullptr;
     void* d_craters = nullptr;
     void* d_crater_masks = nullptr;
     uint32_t n_nodes = 0, n_analytic = 0, n_sdf = 0;
-    int depth = 0;
+    int depth = 0;        // levels of the two-child tree the builders made
+    int stack_need = 0;   // traversal stack entries the four-child tree can need
     std::vector<uint8_t> kinds;   // per primitive, for argument checks
     // objects evaluated on the host: their primitive indices in the order of dev.host_boxes, the caller's callbacks
     std::vector<uint32_t> host_prims;
@@ -470,7 +472,7 @@ int enqueue_bounces(mipt_ctx* c, const mipt_scene* sc, const BatchParams& bp, ui
     for (uint32_t b = 0; b < bounces; ++b) {
         const int done = b == 0 ? first_done : 0;
         if (b > 0) launch_latch_cancel(c->stream, c->pb);
-        if (done < 1) { StageTimer t(c, MIPT_STAGE_EXTEND); launch_extend(c->stream, sc->dev, bp, c->pb, b, sc->depth, c->counting); }
+        if (done < 1) { StageTimer t(c, MIPT_STAGE_EXTEND); launch_extend(c->stream, sc->dev, bp, c->pb, b, sc->stack_need, c->counting); }
         if (sc->n_sdf && done < 2) { StageTimer t(c, MIPT_STAGE_SDF_MARCH); launch_sdf_march(c->stream, sc->dev, bp, c->pb, b); }
         if (host && done < 3) {
             const int rc = host_objects_extend(c, sc, b, ht);
@@ -618,7 +620,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
         launch_latch_cancel(c->stream, c->pb);
-        { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate_extend(c->stream, cr, sc->dev, bp, c->pb, cull, sc->depth, c->counting); }
+        { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate_extend(c->stream, cr, sc->dev, bp, c->pb, cull, sc->stack_need, c->counting); }
         if (const int rb = enqueue_bounces(c, sc, bp, st->bounces, 1, &host_totals); rb != MIPT_OK) return rb;
         launch_latch_cancel(c->stream, c->pb);
         { StageTimer t(c, MIPT_STAGE_ACCUMULATE); launch_accumulate(c->stream, bp, c->pb, d_sum); }
@@ -912,21 +914,26 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
         analytic_boxes.push_back(u);
     }
     BvhResult bvh;
-    void* d_lbvh = nullptr;   // nodes built on the device (owned by the scene once it exists)
     if ((flags & MIPT_UPLOAD_DEVICE_BVH) && n_analytic >= 2) {
-        const hipError_t be = build_lbvh_device(c->stream, boxes.data(), n_analytic, analytic_boxes[0].data(), analytic_boxes[0].data() + 3, &d_lbvh, &bvh.depth);
+        // the two-child tree is built on the device, and comes back for the four-child form to be made of it
+        void* d_lbvh = nullptr;
+        hipError_t be = build_lbvh_device(c->stream, boxes.data(), n_analytic, analytic_boxes[0].data(), analytic_boxes[0].data() + 3, &d_lbvh, &bvh.depth);
+        if (be == hipSuccess) {
+            bvh.nodes.resize(n_analytic - 1u);
+            be = hipMemcpy(bvh.nodes.data(), d_lbvh, bvh.nodes.size() * sizeof(BvhNode), hipMemcpyDeviceToHost);
+            (void)hipFree(d_lbvh);
+        }
         if (be != hipSuccess) {
             c->last_hip = static_cast<int>(be);
             return be == hipErrorOutOfMemory ? MIPT_ERR_OUT_OF_MEMORY : MIPT_ERR_HIP;
         }
-        if (bvh.depth < 1 || bvh.depth > 60) {   // the traversal stack holds 60 levels; only a great many coincident boxes get there
-            (void)hipFree(d_lbvh);
-            return MIPT_ERR_TOO_LARGE;
-        }
     } else {
         bvh = build_bvh(std::move(boxes));
     }
-    const uint32_t n_nodes = d_lbvh ? n_analytic - 1u : static_cast<uint32_t>(bvh.nodes.size());
+    const uint32_t n_nodes = static_cast<uint32_t>(bvh.nodes.size());
+    Bvh4Result bvh4 = collapse_bvh4(bvh.nodes.data(), bvh.nodes.size(), n);
+    // the deepest traversal stack the kernels carry; only a great many coincident boxes get there
+    if (bvh.depth > 60 || bvh4.stack_need > kMaxTraversalStack) return MIPT_ERR_TOO_LARGE;
 
     // Big craters of each crater ball (for_each_nearby_scattered_point at scale 2, PathTracerDemo.cpp:375-409):
     // which lattice cells pass the shell test depends on the ball's offset alone.  The device evaluates the
@@ -939,7 +946,6 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
         constexpr size_t kCells = size_t(kCube) * kCube * kCube;
         float* d_cells = nullptr;
         if (const hipError_t me = hipMalloc(reinterpret_cast<void**>(&d_cells), kCells * 12 * sizeof(float)); me != hipSuccess) {
-            if (d_lbvh) (void)hipFree(d_lbvh);
             c->last_hip = static_cast<int>(me);
             return MIPT_ERR_HIP;
         }
@@ -951,8 +957,7 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
             for (int a = 0; a < 3; ++a) {
                 if (!(std::fabs(r.p[a]) < 4.0e6f)) {   // lattice coordinates must stay exact 24-bit integers
                     (void)hipFree(d_cells);
-                    if (d_lbvh) (void)hipFree(d_lbvh);
-                    return MIPT_ERR_ARGUMENT;
+                            return MIPT_ERR_ARGUMENT;
                 }
                 base[a] = static_cast<int>(std::floor(r.p[a])) - 4;
             }
@@ -961,8 +966,7 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
             if (ce == hipSuccess) ce = hipStreamSynchronize(c->stream);
             if (ce != hipSuccess) {
                 (void)hipFree(d_cells);
-                if (d_lbvh) (void)hipFree(d_lbvh);
-                c->last_hip = static_cast<int>(ce);
+                    c->last_hip = static_cast<int>(ce);
                 return MIPT_ERR_HIP;
             }
             const uint32_t first = static_cast<uint32_t>(craters.size() / 12);
@@ -971,8 +975,7 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
             const uint32_t count = static_cast<uint32_t>(craters.size() / 12) - first;
             if (count > 64) {   // one crater per lane; the shell holds ~32 cells for any offset (23..39 seen)
                 (void)hipFree(d_cells);
-                if (d_lbvh) (void)hipFree(d_lbvh);
-                return MIPT_ERR_TOO_LARGE;
+                    return MIPT_ERR_TOO_LARGE;
             }
             // cell -> crater mask: crater c is visited from a query in cell f iff cell_c - f is -1, 0, 1 or 2 on every
             // axis (for_each_nearby_scattered_point with radius 2, PathTracerDemo.cpp:87-93)
@@ -998,12 +1001,8 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
     }
 
     auto* s = new (std::nothrow) mipt_scene;
-    if (!s) {
-        if (d_lbvh) (void)hipFree(d_lbvh);
-        return MIPT_ERR_OUT_OF_MEMORY;
-    }
+    if (!s) return MIPT_ERR_OUT_OF_MEMORY;
     s->device = c->device;
-    s->d_nodes = d_lbvh;
     auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
         if (bytes == 0) return hipSuccess;
         hipError_t e = hipMalloc(dst, bytes);
@@ -1013,7 +1012,8 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
     hipError_t e = upload(&s->d_prims, prims.data(), prims.size() * sizeof(PrimRec));
     if (e == hipSuccess) e = upload(&s->d_tri, tri_c.data(), tri_c.size() * sizeof(float));
     if (e == hipSuccess) e = upload(&s->d_mats, mats.data(), mats.size() * sizeof(MaterialRec));
-    if (e == hipSuccess && !d_lbvh) e = upload(&s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode));
+    if (e == hipSuccess) e = upload(&s->d_nodes, bvh4.nodes.data(), bvh4.nodes.size() * sizeof(Bvh4Node));
+    if (e == hipSuccess && !bvh4.nodes.empty()) e = upload(&s->d_leaf_boxes, bvh4.leaf_boxes.data(), bvh4.leaf_boxes.size() * sizeof(float));
     if (e == hipSuccess) e = upload(&s->d_sdf, sdf.data(), sdf.size() * sizeof(SdfBox));
     if (e == hipSuccess) e = upload(&s->d_host_boxes, host_boxes.data(), host_boxes.size() * sizeof(SdfBox));
     // noise() (PathTracerDemo.cpp:56-70) applies the transform T = (L, t), samples, scales by 1.1 and
@@ -1054,7 +1054,8 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
     s->dev.prims = static_cast<const PrimRec*>(s->d_prims);
     s->dev.tri_c = static_cast<const float*>(s->d_tri);
     s->dev.materials = static_cast<const MaterialRec*>(s->d_mats);
-    s->dev.nodes = static_cast<const BvhNode*>(s->d_nodes);
+    s->dev.nodes = static_cast<const Bvh4Node*>(s->d_nodes);
+    s->dev.leaf_boxes = static_cast<const float*>(s->d_leaf_boxes);
     s->dev.sdf_boxes = static_cast<const SdfBox*>(s->d_sdf);
     s->dev.noise_oct = static_cast<const float*>(s->d_oct);
     s->dev.noise_raw = s->d_oct ? static_cast<const float*>(s->d_oct) + 8 * 13 : nullptr;
@@ -1113,6 +1114,7 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
     s->n_analytic = n_analytic;
     s->n_sdf = static_cast<uint32_t>(sdf.size());
     s->depth = bvh.depth;
+    s->stack_need = bvh4.stack_need;
     *out = s;
     return MIPT_OK;
 }
@@ -1121,7 +1123,7 @@ void mipt_scene_free(mipt_scene* s) {
     if (!s) return;
     // hipFree waits for work that still uses the memory; the context may already be gone
     (void)hipSetDevice(s->device);
-    for (void* p : {s->d_prims, s->d_tri, s->d_mats, s->d_nodes, s->d_sdf, s->d_oct, s->d_craters, s->d_crater_masks, s->d_host_boxes})
+    for (void* p : {s->d_prims, s->d_tri, s->d_mats, s->d_nodes, s->d_leaf_boxes, s->d_sdf, s->d_oct, s->d_craters, s->d_crater_masks, s->d_host_boxes})
         if (p) (void)hipFree(p);
     delete s;
 }
@@ -1291,7 +1293,7 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->pb.hit_key, 0xff, n * 8, c->stream));   // the fused kernel stores hits only
     launch_latch_cancel(c->stream, c->pb);
-    launch_generate_extend(c->stream, pack_camera(c0), sc->dev, bp, c->pb, screen_rects(sc, c0, width, height), sc->depth);
+    launch_generate_extend(c->stream, pack_camera(c0), sc->dev, bp, c->pb, screen_rects(sc, c0, width, height), sc->stack_need);
     if (sc->n_sdf) launch_sdf_march(c->stream, sc->dev, bp, c->pb, 0);
     if (!sc->host_prims.empty()) {
         Totals unused{};
@@ -1347,7 +1349,7 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     std::vector<unsigned long long> keys;
     if (out_first_prim || out_first_t) {
         // first closest hit, before shading overwrites the rays
-        launch_extend(c->stream, sc->dev, bp, c->pb, 0, sc->depth);
+        launch_extend(c->stream, sc->dev, bp, c->pb, 0, sc->stack_need);
         if (sc->n_sdf) launch_sdf_march(c->stream, sc->dev, bp, c->pb, 0);
         if (!sc->host_prims.empty()) {
             Totals unused{};

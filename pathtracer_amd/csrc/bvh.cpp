@@ -187,4 +187,97 @@ BvhResult build_bvh(std::vector<BuildBox> boxes, int max_depth) {
     return r;
 }
 
+namespace {
+
+struct Collapser {
+    const BvhNode* in;
+    Bvh4Result& out;
+
+    struct Entry {
+        float lo[3], hi[3];
+        int32_t link;
+    };
+    static Entry entry_of(const BvhNode& n, int side) {
+        Entry e;
+        std::memcpy(e.lo, side == 0 ? n.lo0 : n.lo1, sizeof(e.lo));
+        std::memcpy(e.hi, side == 0 ? n.hi0 : n.hi1, sizeof(e.hi));
+        e.link = side == 0 ? n.child0 : n.child1;
+        return e;
+    }
+    static bool absent(const Entry& e) { return e.lo[0] == std::numeric_limits<float>::infinity(); }
+    static float half_area(const Entry& e) {
+        const float x = e.hi[0] - e.lo[0], y = e.hi[1] - e.lo[1], z = e.hi[2] - e.lo[2];
+        return x * y + y * z + z * x;
+    }
+
+    // Emits the four-child node for two-child node `n2` at index `self` (already allocated); returns the stack
+    // entries a walk of its subtree can hold at once.
+    int emit(int32_t n2, int32_t self, int level) {
+        out.depth = std::max(out.depth, level);
+        Entry kids[4];
+        int n_kids = 0;
+        for (int side = 0; side < 2; ++side) {
+            const Entry e = entry_of(in[n2], side);
+            if (!absent(e)) kids[n_kids++] = e;
+        }
+        while (n_kids < 4) {
+            int open = -1;
+            for (int k = 0; k < n_kids; ++k)
+                if (kids[k].link >= 0 && (open < 0 || half_area(kids[k]) > half_area(kids[open]))) open = k;
+            if (open < 0) break;
+            const BvhNode& g = in[kids[open].link];
+            kids[open] = entry_of(g, 0);   // the tree builders give every inner node two real children
+            kids[n_kids++] = entry_of(g, 1);
+        }
+        const float inf = std::numeric_limits<float>::infinity();
+        // a node's inner children get consecutive indices: they are what is visited next
+        int32_t child_nodes[4];
+        for (int k = 0; k < 4; ++k) {
+            child_nodes[k] = -1;
+            if (k < n_kids && kids[k].link >= 0) {
+                child_nodes[k] = static_cast<int32_t>(out.nodes.size());
+                out.nodes.emplace_back();
+            }
+        }
+        Bvh4Node& nd = out.nodes[self];
+        for (int k = 0; k < 4; ++k) {
+            const bool have = k < n_kids;
+            nd.lox[k] = have ? kids[k].lo[0] : inf;
+            nd.loy[k] = have ? kids[k].lo[1] : inf;
+            nd.loz[k] = have ? kids[k].lo[2] : inf;
+            nd.hix[k] = have ? kids[k].hi[0] : inf;
+            nd.hiy[k] = have ? kids[k].hi[1] : inf;
+            nd.hiz[k] = have ? kids[k].hi[2] : inf;
+            nd.pad[k] = 0;
+            if (!have) {
+                nd.child[k] = kBvh4Absent;
+            } else if (kids[k].link < 0) {
+                nd.child[k] = kids[k].link;
+                float* lb = out.leaf_boxes.data() + 8 * static_cast<size_t>(~kids[k].link);
+                std::memcpy(lb, kids[k].lo, 12);
+                std::memcpy(lb + 4, kids[k].hi, 12);
+            } else {
+                nd.child[k] = child_nodes[k];
+            }
+        }
+        int need = n_kids - 1;
+        for (int k = 0; k < n_kids; ++k)
+            if (child_nodes[k] >= 0) need = std::max(need, n_kids - 1 + emit(kids[k].link, child_nodes[k], level + 1));
+        return need;
+    }
+};
+
+}   // namespace
+
+Bvh4Result collapse_bvh4(const BvhNode* nodes2, size_t n_nodes2, uint32_t n_prims) {
+    Bvh4Result r;
+    if (n_nodes2 == 0) return r;
+    r.leaf_boxes.assign(8 * static_cast<size_t>(n_prims), 0.0f);
+    r.nodes.reserve(n_nodes2 / 2 + 1);
+    r.nodes.emplace_back();
+    Collapser c{nodes2, r};
+    r.stack_need = std::max(1, c.emit(0, 0, 1));
+    return r;
+}
+
 }   // namespace mipt

@@ -3,6 +3,7 @@
 // (src/ObjectTree.cpp:90-184), whose cost grows like N^2.6; because the reference's tree never
 // culls, every topology returns the same closest hit.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include <vector>
@@ -24,5 +25,16 @@ struct BvhResult {
 // max_depth bounds the tree height (and with it the traversal stack); deeper subtrees fall back to
 // median splits, which always fit.
 BvhResult build_bvh(std::vector<BuildBox> boxes, int max_depth = 60);
+
+// The four-child tree the kernels walk, made from a two-child tree by pulling grandchildren up: a node's child
+// list starts as the two children and, while it has fewer than four entries, the inner entry with the largest
+// surface area is replaced by its own two children.
+struct Bvh4Result {
+    std::vector<Bvh4Node> nodes;
+    std::vector<float> leaf_boxes;   // 8 floats per primitive index below n_prims (zeros for primitives not in the tree)
+    int depth = 0;                   // node levels
+    int stack_need = 0;              // entries a depth-first walk that defers up to three children per node can hold at once
+};
+Bvh4Result collapse_bvh4(const BvhNode* nodes2, size_t n_nodes2, uint32_t n_prims);
 
 }   // namespace mipt

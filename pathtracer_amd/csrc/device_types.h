@@ -36,6 +36,18 @@ struct alignas(64) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
+// Four-child node, the form the traversal kernels walk (128 bytes, one cache line): one coordinate of all four
+// children's boxes per dwordx4, then the links.  child >= 0: node index; kBvh4Absent: no child (its box lies at
+// +infinity on every axis, which no ray reaches); any other negative value: leaf holding primitive ~child.
+struct alignas(128) Bvh4Node {
+    float lox[4], loy[4], loz[4];
+    float hix[4], hiy[4], hiz[4];
+    int32_t child[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
+constexpr int32_t kBvh4Absent = INT32_MIN;
+
 // World box of one SDF primitive (tested by every ray after the analytic traversal).
 struct SdfBox {
     float lo[3];
@@ -54,7 +66,10 @@ struct SceneDev {
     const PrimRec* prims;
     const float* tri_c;            // 3 floats per primitive, only read for triangles (may be null)
     const MaterialRec* materials;
-    const BvhNode* nodes;          // null when the scene has no analytic primitive
+    const Bvh4Node* nodes;         // null when the scene has no analytic primitive
+    // world box of every analytic primitive as its BVH leaf holds it, 8 floats {lo.xyz, -, hi.xyz, -} at 8 * prim: lets
+    // a leaf that waited on a traversal stack be tested against the limit the ray has reached since
+    const float* leaf_boxes;
     const SdfBox* sdf_boxes;
     uint32_t n_sdf;
     uint32_t n_prims;

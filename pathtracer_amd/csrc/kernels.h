@@ -65,9 +65,11 @@ struct CullRects {
 
 // generate + first extend fused; needs counters zeroed; fills queue[0] and the SDF queue of bounce 0
 // `count`: the counting build of the traversal (same steps, same order; adds node visits and primitive tests to Totals)
-void launch_generate_extend(hipStream_t, const CameraRec&, const SceneDev&, const BatchParams&, const PathBuffers&, const CullRects&, int bvh_depth,
+// stack_need: the traversal stack entries the scene's tree can need (at most kMaxTraversalStack)
+constexpr int kMaxTraversalStack = 60;
+void launch_generate_extend(hipStream_t, const CameraRec&, const SceneDev&, const BatchParams&, const PathBuffers&, const CullRects&, int stack_need,
                             bool count = false);
-void launch_extend(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, int bvh_depth, bool count = false);
+void launch_extend(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, int stack_need, bool count = false);
 // big-crater candidates of a crater ball: 12 floats per cell of the n^3 lattice cube at `base` (x-major)
 void launch_crater_cells(hipStream_t, const float off[3], const int base[3], int n, float* out);
 void launch_sdf_march(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce);

@@ -377,27 +377,29 @@ __device__ __forceinline__ void camera_ray(const CameraRec& cam, const BatchPara
 // =============================================================================================
 // Closest hit over the analytic primitives: ObjectTree::Tree::hit (src/ObjectTree.cpp:22-88) with real
 // culling, as a per-lane state machine that a wave steps in two phases:
-//   * inner step -- visit one BVH2 node: slab-test both children against the current limit, nearer first;
-//     children that are leaves become the lane's pending leaves, of the others one is visited next and
-//     one goes on the lane's stack (a column of LDS dwords: entry e of lane l at e * 256 + l,
-//     conflict-free);
-//   * leaf step -- Object::hitRay on the pending leaves.  A wave runs it when enough lanes have leaves
+//   * inner step -- visit one four-child node: slab-test the four boxes against the current limit and order
+//     the hits by entry distance; the nearest is taken next (a node to visit, or a leaf that becomes the
+//     lane's pending leaf), the others go on the lane's stack, farthest first (a column of LDS dwords:
+//     entry e of lane l at e * 256 + l, conflict-free);
+//   * leaf step -- Object::hitRay on the pending leaf.  A wave runs it when enough lanes have a leaf
 //     pending (or none can do anything else), so the long exact intersection code runs with most lanes
 //     active instead of once per lane that happens to reach a leaf.
+// A stack entry carries no distance: a node taken off the stack is tested against the limit when it is
+// visited (its children's boxes lie inside its own), a leaf by its own box, kept per primitive.
 // A lane whose ray is finished takes the next ray at once (the kernels below refill idle lanes), so a
 // wave is not held up by its longest ray.  Hits are ranked by t = (hit - o).d as the reference ranks
 // them; boxes are culled in ray-parameter units, t / |d|^2, with a relative and an absolute margin.
 // =============================================================================================
 struct Trav {
     f3 o, d, inv_d;
-    float inv_len2, limit, tn_cur, tn_leaf1;
+    float inv_len2, limit;
     unsigned long long best;
     f3 best_pos;
-    int cur;            // >= 0: node to visit (once no leaf is pending); kTravNone: nothing chosen yet
-    int leaf0, leaf1;   // pending leaves (primitive indices) or kTravNone; leaf1 is the farther one
+    int cur;     // >= 0: node to visit (once no leaf is pending); kTravNone: nothing chosen
+    int leaf;    // pending leaf (primitive index) or kTravNone
     int sp;
     uint32_t slot;
-    bool busy;          // holds a ray
+    bool busy;   // holds a ray
 };
 constexpr int kTravNone = -1;
 
@@ -407,60 +409,115 @@ __device__ __forceinline__ void trav_begin(Trav& t, f3 o, f3 d, uint32_t slot, b
     t.inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     t.inv_len2 = 1.0f / norm_sq(d);
     t.limit = 3.0e38f;
-    t.tn_cur = 0.0f;
     t.best = kMissKey;
     t.best_pos = mk3(0.0f, 0.0f, 0.0f);
     t.cur = has_nodes ? 0 : kTravNone;
-    t.leaf0 = t.leaf1 = kTravNone;
+    t.leaf = kTravNone;
     t.sp = 0;
     t.slot = slot;
     t.busy = true;
 }
-__device__ __forceinline__ bool trav_wants_inner(const Trav& t) { return t.busy && t.cur >= 0 && t.leaf0 == kTravNone; }
-__device__ __forceinline__ bool trav_wants_leaf(const Trav& t) { return t.busy && t.leaf0 != kTravNone; }
-__device__ __forceinline__ bool trav_finished(const Trav& t) { return t.busy && t.cur == kTravNone && t.leaf0 == kTravNone; }
+__device__ __forceinline__ bool trav_wants_inner(const Trav& t) { return t.busy && t.cur >= 0 && t.leaf == kTravNone; }
+__device__ __forceinline__ bool trav_wants_leaf(const Trav& t) { return t.busy && t.leaf != kTravNone; }
+__device__ __forceinline__ bool trav_finished(const Trav& t) { return t.busy && t.cur == kTravNone && t.leaf == kTravNone && t.sp == 0; }
 
-// After a visit or a leaf step: drop a chosen node that the limit has overtaken, then take the next one
-// from the stack if nothing is chosen.
-__device__ __forceinline__ void trav_advance(Trav& t, const int* stack) {
-    if (t.cur >= 0 && t.tn_cur > t.limit) t.cur = kTravNone;
-    if (t.cur == kTravNone && t.sp > 0) {
+// Nothing chosen: take entries off the stack until one is a node, or a leaf whose box the limit still reaches.
+__device__ __forceinline__ void trav_pop(const SceneDev& sc, Trav& t, const int* stack) {
+    while (t.busy && t.cur == kTravNone && t.leaf == kTravNone && t.sp > 0) {
         --t.sp;
-        t.cur = stack[t.sp * 256];
-        t.tn_cur = 0.0f;   // its box is tested against the limit when it is visited
+        const int e = stack[t.sp * 256];
+        if (e >= 0) {
+            t.cur = e;
+        } else {
+            const float4* lb = reinterpret_cast<const float4*>(sc.leaf_boxes) + 2 * static_cast<size_t>(~e);
+            const float4 lo = lb[0], hi = lb[1];
+            float tn;
+            if (slab(t.o, t.inv_d, &lo.x, &hi.x, t.limit, tn)) t.leaf = ~e;
+        }
     }
 }
 
+// Orders two (distance, link) pairs, the nearer first.
+__device__ __forceinline__ void trav_order(float& ta, int& ca, float& tb, int& cb) {
+    const bool sw = tb < ta;
+    const float tl = sw ? tb : ta, th = sw ? ta : tb;
+    const int cl = sw ? cb : ca, ch = sw ? ca : cb;
+    ta = tl;
+    tb = th;
+    ca = cl;
+    cb = ch;
+}
+
+// Entry distance of the ray into each of two boxes given the boxes' near and far planes per axis (already picked by
+// the sign of the ray's direction), or `far` for a box the ray misses or enters beyond `limit`.  The same arithmetic
+// as slab(), two boxes at a time so that the subtractions and multiplications are packed instructions.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 slab_pair(f2 nx, f2 ny, f2 nz, f2 fx, f2 fy, f2 fz, f3 o, f3 inv_d, float limit, float far) {
+    const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const f2 ix = {inv_d.x, inv_d.x}, iy = {inv_d.y, inv_d.y}, iz = {inv_d.z, inv_d.z};
+    const f2 ax = (nx - ox) * ix, ay = (ny - oy) * iy, az = (nz - oz) * iz;
+    const f2 bx = (fx - ox) * ix, by = (fy - oy) * iy, bz = (fz - oz) * iz;
+    const f2 grow = {1.0000005f, 1.0000005f};
+    f2 tn, tf;
+    tn.x = fmaxf(fmaxf(ax.x, ay.x), fmaxf(az.x, 0.0f));
+    tn.y = fmaxf(fmaxf(ax.y, ay.y), fmaxf(az.y, 0.0f));
+    tf.x = fminf(fminf(bx.x, by.x), bz.x);
+    tf.y = fminf(fminf(bx.y, by.y), bz.y);
+    tf = tf * grow;
+    f2 r;
+    r.x = (tn.x <= tf.x && tn.x <= limit) ? tn.x : far;
+    r.y = (tn.y <= tf.y && tn.y <= limit) ? tn.y : far;
+    return r;
+}
+
 __device__ __forceinline__ void trav_inner_step(const SceneDev& sc, Trav& t, int* stack) {
-    const float4* np = reinterpret_cast<const float4*>(sc.nodes + t.cur);
-    const float4 a = np[0], b = np[1], c = np[2], e = np[3];
-    const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y};
-    const float lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
-    const int c0 = __float_as_int(e.x), c1 = __float_as_int(e.y);
-    float t0, t1;
-    const bool h0 = slab(t.o, t.inv_d, lo0, hi0, t.limit, t0);
-    const bool h1 = slab(t.o, t.inv_d, lo1, hi1, t.limit, t1);
+    // Of each axis' two planes the ray crosses the one on the side it comes from first: which of the node's
+    // low / high rows holds a box's near plane depends on the sign of the direction alone, so each lane reads
+    // near and far rows by its own offsets and no per-box minimum / maximum is needed.  Rows: lox at byte 0,
+    // loy 16, loz 32, hix 48, hiy 64, hiz 80 of the node; near ^ mask is the far row.
+    const char* base = reinterpret_cast<const char*>(sc.nodes);
+    const uint32_t at = static_cast<uint32_t>(t.cur) << 7;
+    const uint32_t near_x = at + (t.inv_d.x < 0.0f ? 48u : 0u);
+    const uint32_t near_y = at + (t.inv_d.y < 0.0f ? 64u : 16u);
+    const uint32_t near_z = at + (t.inv_d.z < 0.0f ? 80u : 32u);
+    const float4 nx = *reinterpret_cast<const float4*>(base + near_x), fx = *reinterpret_cast<const float4*>(base + (near_x ^ 48u));
+    const float4 ny = *reinterpret_cast<const float4*>(base + near_y), fy = *reinterpret_cast<const float4*>(base + (near_y ^ 80u));
+    const float4 nz = *reinterpret_cast<const float4*>(base + near_z), fz = *reinterpret_cast<const float4*>(base + (near_z ^ 112u));
+    const int4 ch = *reinterpret_cast<const int4*>(base + (at + 96u));
     // Everything below is selects rather than branches: the lanes of a wave take every combination of
     // hit / miss and leaf / node at once, and a branch per case costs more than computing all of them.
-    // Order the children, the nearer hit first (a lone hit counts as the first).
-    const bool sw = h1 && (!h0 || t1 < t0);
-    const int ca = sw ? c1 : c0, cb = sw ? c0 : c1;
-    const float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
-    const bool ha = h0 || h1, hb = h0 && h1;
-    const bool leaf_a = ha && ca < 0, node_a = ha && ca >= 0;
-    const bool leaf_b = hb && cb < 0, node_b = hb && cb >= 0;
-    // hit leaves become the lane's pending leaves (none is pending on entry), hit nodes: one is visited next ...
-    t.leaf0 = leaf_a ? ~ca : (leaf_b ? ~cb : kTravNone);
-    t.leaf1 = (leaf_a && leaf_b) ? ~cb : kTravNone;
-    t.tn_leaf1 = tb;
-    t.cur = node_a ? ca : (node_b ? cb : kTravNone);
-    t.tn_cur = node_a ? ta : tb;
-    // ... and the other goes on the lane's stack
-    if (node_a && node_b) {
-        stack[t.sp * 256] = cb;
+    const float far = 3.4e38f;
+    // (origin and reciprocal direction as six values of their own: left grouped in threes, the compiler regroups
+    // them for the packed arithmetic through memory)
+    asm volatile("" : "+v"(t.o.x), "+v"(t.o.y), "+v"(t.o.z), "+v"(t.inv_d.x), "+v"(t.inv_d.y), "+v"(t.inv_d.z));
+    const f2 t01 = slab_pair(f2{nx.x, nx.y}, f2{ny.x, ny.y}, f2{nz.x, nz.y}, f2{fx.x, fx.y}, f2{fy.x, fy.y}, f2{fz.x, fz.y}, t.o, t.inv_d, t.limit, far);
+    const f2 t23 = slab_pair(f2{nx.z, nx.w}, f2{ny.z, ny.w}, f2{nz.z, nz.w}, f2{fx.z, fx.w}, f2{fy.z, fy.w}, f2{fz.z, fz.w}, t.o, t.inv_d, t.limit, far);
+    float t0 = t01.x, t1 = t01.y, t2 = t23.x, t3 = t23.y;
+    // a child that is not hit is ordered last and marked absent (an entry distance is far below 3.4e38:
+    // limits start at 3e38)
+    int c0 = t0 < far ? ch.x : kBvh4Absent, c1 = t1 < far ? ch.y : kBvh4Absent;
+    int c2 = t2 < far ? ch.z : kBvh4Absent, c3 = t3 < far ? ch.w : kBvh4Absent;
+    trav_order(t0, c0, t1, c1);
+    trav_order(t2, c2, t3, c3);
+    trav_order(t0, c0, t2, c2);
+    trav_order(t1, c1, t3, c3);
+    trav_order(t1, c1, t2, c2);
+    // the farther hits wait on the stack, the farthest at the bottom
+    if (c3 != kBvh4Absent) {
+        stack[t.sp * 256] = c3;
         ++t.sp;
     }
-    if (t.leaf0 == kTravNone) trav_advance(t, stack);
+    if (c2 != kBvh4Absent) {
+        stack[t.sp * 256] = c2;
+        ++t.sp;
+    }
+    if (c1 != kBvh4Absent) {
+        stack[t.sp * 256] = c1;
+        ++t.sp;
+    }
+    // the nearest is next: a node to visit or a leaf to test
+    t.cur = c0 >= 0 ? c0 : kTravNone;
+    t.leaf = (c0 < 0 && c0 != kBvh4Absent) ? ~c0 : kTravNone;
 }
 
 __device__ __forceinline__ void trav_test_leaf(const SceneDev& sc, Trav& t, uint32_t prim) {
@@ -478,15 +535,9 @@ __device__ __forceinline__ void trav_test_leaf(const SceneDev& sc, Trav& t, uint
     }
 }
 
-// One pending leaf per call (the nearer first; the farther one only if the limit still reaches its box).
-__device__ __forceinline__ void trav_leaf_step(const SceneDev& sc, Trav& t, const int* stack) {
-    trav_test_leaf(sc, t, static_cast<uint32_t>(t.leaf0));
-    t.leaf0 = kTravNone;
-    if (t.leaf1 != kTravNone) {
-        if (!(t.tn_leaf1 > t.limit)) t.leaf0 = t.leaf1;
-        t.leaf1 = kTravNone;
-    }
-    if (t.leaf0 == kTravNone) trav_advance(t, stack);
+__device__ __forceinline__ void trav_leaf_step(const SceneDev& sc, Trav& t) {
+    trav_test_leaf(sc, t, static_cast<uint32_t>(t.leaf));
+    t.leaf = kTravNone;
 }
 
 // Steps the wave's rays until fewer than `keep_busy` lanes hold an unfinished ray (so the caller can
@@ -501,14 +552,15 @@ template <bool COUNT>
 __device__ __forceinline__ void trav_run(const SceneDev& sc, Trav& t, int* stack, uint32_t keep_busy, TravCounts& counts, uint32_t kLeafQuorum = 20u) {
     // kLeafQuorum: lanes with a pending leaf that make a leaf step worth its cost
     for (;;) {
+        trav_pop(sc, t, stack);
         if (trav_wants_inner(t)) {
             trav_inner_step(sc, t, stack);
             if (COUNT) ++counts.nodes;
         }
         const uint32_t n_leaf = static_cast<uint32_t>(__popcll(__ballot(trav_wants_leaf(t))));
-        if (n_leaf >= kLeafQuorum || (n_leaf > 0 && !__ballot(trav_wants_inner(t)))) {
+        if (n_leaf >= kLeafQuorum || (n_leaf > 0 && !__ballot(t.busy && t.leaf == kTravNone && (t.cur >= 0 || t.sp > 0)))) {
             if (trav_wants_leaf(t)) {
-                trav_leaf_step(sc, t, stack);
+                trav_leaf_step(sc, t);
                 if (COUNT) ++counts.prims;
             }
         }
@@ -768,7 +820,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
     __shared__ int s_stack[STACK * 256];
     // one atomic on the SDF queue's counter per `kCap` entries of a wave (that counter is one address for the
     // whole chip): as many as the traversal stacks leave room for
-    constexpr uint32_t kCap = STACK <= 8 ? 1024 : STACK <= 24 ? 512 : STACK <= 40 ? 256 : 128;
+    constexpr uint32_t kCap = STACK <= 8 ? 1024 : STACK <= 24 ? 512 : STACK <= 32 ? 256 : 128;
     __shared__ uint32_t s_pend[4 * kCap];
     PendingQueue to_sdf{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u};
     const uint32_t n = pb.counters[bounce].n_live;
@@ -1621,7 +1673,7 @@ static inline uint32_t grid_for(size_t n, uint32_t cap = 256u * 32u) {
 }
 
 void launch_generate_extend(hipStream_t st, const CameraRec& cam, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, const CullRects& cull,
-                            int bvh_depth, bool count) {
+                            int stack_need, bool count) {
     // one thread per pixel; enough sample stripes to fill the chip when the image is small
     const uint32_t bx = (bp.n_pix + 255u) / 256u, samples = bp.n_slots / bp.n_pix;
     const uint32_t by = std::max(1u, std::min(samples, (4096u + bx - 1u) / bx));
@@ -1632,14 +1684,15 @@ void launch_generate_extend(hipStream_t st, const CameraRec& cam, const SceneDev
         if (count) hipLaunchKernelGGL((k_generate_extend<STACK, CAP, true>), grid, block, 0, st, cam, sc, bp, pb, cull);  \
         else hipLaunchKernelGGL((k_generate_extend<STACK, CAP, false>), grid, block, 0, st, cam, sc, bp, pb, cull);       \
     } while (0)
-    if (bvh_depth <= 8) MIPT_LAUNCH_GE(8, 1024);
-    else if (bvh_depth <= 24) MIPT_LAUNCH_GE(24, 512);
-    else if (bvh_depth <= 40) MIPT_LAUNCH_GE(40, 256);
+    if (stack_need <= 8) MIPT_LAUNCH_GE(8, 1024);
+    else if (stack_need <= 24) MIPT_LAUNCH_GE(24, 512);
+    else if (stack_need <= 32) MIPT_LAUNCH_GE(32, 512);
+    else if (stack_need <= 48) MIPT_LAUNCH_GE(48, 256);
     else MIPT_LAUNCH_GE(60, 128);
 #undef MIPT_LAUNCH_GE
 }
 
-void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, int bvh_depth, bool count) {
+void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, int stack_need, bool count) {
     // persistent waves: every wave drains the queue
     const dim3 grid(256u * 4u), block(256);
 #define MIPT_LAUNCH_EX(STACK)                                                                          \
@@ -1647,9 +1700,10 @@ void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, co
         if (count) hipLaunchKernelGGL((k_extend<STACK, true>), grid, block, 0, st, sc, bp, pb, bounce); \
         else hipLaunchKernelGGL((k_extend<STACK, false>), grid, block, 0, st, sc, bp, pb, bounce);      \
     } while (0)
-    if (bvh_depth <= 8) MIPT_LAUNCH_EX(8);
-    else if (bvh_depth <= 24) MIPT_LAUNCH_EX(24);
-    else if (bvh_depth <= 40) MIPT_LAUNCH_EX(40);
+    if (stack_need <= 8) MIPT_LAUNCH_EX(8);
+    else if (stack_need <= 24) MIPT_LAUNCH_EX(24);
+    else if (stack_need <= 32) MIPT_LAUNCH_EX(32);
+    else if (stack_need <= 48) MIPT_LAUNCH_EX(48);
     else MIPT_LAUNCH_EX(60);
 #undef MIPT_LAUNCH_EX
 }
