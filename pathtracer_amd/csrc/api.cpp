@@ -55,7 +55,7 @@ struct mipt_ctx {
     bool device_bvh = false;        // MIPT_DEVICE_BVH=1: mipt_scene_upload builds the tree on the GPU
     bool full_march = false;        // MIPT_FULL_MARCH=1: no shortcut for SDF marches that cannot end (for the equivalence test)
     uint32_t lane_threshold = 14;   // MIPT_LANE_THRESHOLD: 1 = always one point per lane, 65 = never
-    uint32_t trav_quorum = 20, trav_keep = 48;   // MIPT_LEAF_QUORUM, MIPT_KEEP_BUSY: scheduling of the BVH traversal's two phases (tuning aids)
+    uint32_t trav_quorum = 20, trav_quorum_primary = 2, trav_keep = 40;   // MIPT_LEAF_QUORUM, MIPT_LEAF_QUORUM_PRIMARY, MIPT_KEEP_BUSY: scheduling of the BVH traversal's two phases (tuning aids)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // optional per-launch timing
@@ -616,6 +616,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.flags = (st->flags & static_cast<uint32_t>(MIPT_FLAG_NO_JITTER)) | (c->full_march ? kFlagFullMarch : 0u);
         bp.lane_threshold = c->lane_threshold;
     bp.trav_quorum = c->trav_quorum;
+    bp.trav_quorum_primary = c->trav_quorum_primary;
     bp.trav_keep = c->trav_keep;
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
@@ -722,6 +723,7 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
     if (const char* e = std::getenv("MIPT_FULL_MARCH")) c->full_march = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_DEVICE_BVH")) c->device_bvh = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_LEAF_QUORUM")) c->trav_quorum = static_cast<uint32_t>(std::min(64L, std::max(1L, std::atol(e))));
+    if (const char* e = std::getenv("MIPT_LEAF_QUORUM_PRIMARY")) c->trav_quorum_primary = static_cast<uint32_t>(std::min(64L, std::max(1L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_KEEP_BUSY")) c->trav_keep = static_cast<uint32_t>(std::min(64L, std::max(0L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_LANE_THRESHOLD")) {
         const long v = std::atol(e);
@@ -1287,6 +1289,7 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     bp.flags = MIPT_FLAG_NO_JITTER | (c->full_march ? kFlagFullMarch : 0u);
     bp.lane_threshold = c->lane_threshold;
     bp.trav_quorum = c->trav_quorum;
+    bp.trav_quorum_primary = c->trav_quorum_primary;
     bp.trav_keep = c->trav_keep;
     mipt_camera c0 = *cam;
     c0.blur_radius = 0.0f;
@@ -1340,6 +1343,7 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     bp.height = 1;
     bp.lane_threshold = c->lane_threshold;
     bp.trav_quorum = c->trav_quorum;
+    bp.trav_quorum_primary = c->trav_quorum_primary;
     bp.trav_keep = c->trav_keep;
     bp.flags = c->full_march ? kFlagFullMarch : 0u;
     bp.seed = seed;

@@ -50,7 +50,8 @@ struct BatchParams {
     uint32_t flags;
     uint32_t lane_threshold;   // SDF near field: waiting lanes from which a wave evaluates one point per lane
     uint32_t trav_quorum;      // BVH traversal: lanes with a pending leaf from which a wave runs a leaf step (20)
-    uint32_t trav_keep;        // BVH traversal: a wave refills its idle lanes when fewer than trav_keep / 64 of its busy lanes are unfinished (48)
+    uint32_t trav_quorum_primary;   // the same for camera rays, whose waves hold neighbouring pixels and reach their leaves together (2)
+    uint32_t trav_keep;        // BVH traversal: a wave refills its idle lanes when fewer than trav_keep / 64 of its busy lanes are unfinished (40)
     uint64_t seed;
 };
 

@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
         // The wave's 64 rays of one sample run to the end together: neighbouring pixels take about equally
         // long, and their queue entries then name 64 consecutive slots, which is what lets the kernels that
         // read the queue later fetch the paths' state in full cache lines.
-        trav_run<COUNT>(sc, t, stack, 0u, counts, bp.trav_quorum);
+        trav_run<COUNT>(sc, t, stack, 0u, counts, bp.trav_quorum_primary);
         // finished rays: keep what hit something or reaches an SDF box
         const bool fin = trav_finished(t);
         bool keep = false, wants_sdf = false;
@@ -1678,7 +1678,8 @@ void launch_generate_extend(hipStream_t st, const CameraRec& cam, const SceneDev
     const uint32_t bx = (bp.n_pix + 255u) / 256u, samples = bp.n_slots / bp.n_pix;
     const uint32_t by = std::max(1u, std::min(samples, (4096u + bx - 1u) / bx));
     const dim3 grid(bx, by), block(256);
-    // (traversal stack, pending-queue capacity): LDS per block = STACK KiB + 8 CAP bytes, at most 64 KiB
+    // (traversal stack, pending-queue capacity): LDS per block = STACK KiB + 32 CAP bytes, at most 64 KiB; four blocks
+    // share a CU's 160 KiB up to 40 KiB each, three up to 53 KiB
 #define MIPT_LAUNCH_GE(STACK, CAP)                                                                                        \
     do {                                                                                                                 \
         if (count) hipLaunchKernelGGL((k_generate_extend<STACK, CAP, true>), grid, block, 0, st, cam, sc, bp, pb, cull);  \
@@ -1686,8 +1687,8 @@ void launch_generate_extend(hipStream_t st, const CameraRec& cam, const SceneDev
     } while (0)
     if (stack_need <= 8) MIPT_LAUNCH_GE(8, 1024);
     else if (stack_need <= 24) MIPT_LAUNCH_GE(24, 512);
-    else if (stack_need <= 32) MIPT_LAUNCH_GE(32, 512);
-    else if (stack_need <= 48) MIPT_LAUNCH_GE(48, 256);
+    else if (stack_need <= 32) MIPT_LAUNCH_GE(32, 256);
+    else if (stack_need <= 48) MIPT_LAUNCH_GE(48, 128);
     else MIPT_LAUNCH_GE(60, 128);
 #undef MIPT_LAUNCH_GE
 }
