@@ -196,11 +196,38 @@ struct Bounce {
     f3 emitted, attenuation, dir;
 };
 
+// The reference's branches (struck from inside; diffuse, specular, transmitted) written so that lanes of one wave
+// that take different branches share the two expensive pieces, the hemisphere sample and the final normalisation,
+// instead of running a copy of each per branch one after the other.  Expressions and the order of the random
+// draws are the reference's.
 __device__ __forceinline__ Bounce deflect(const MaterialRec& m, f3 in, f3 n, Rng& rng) {
     Bounce b;
     const float s = dot(in, n);
-    if (s >= 0.0f) {   // struck from inside
-        const f3 v = unit(in + ((dot(in, n) * (1.0f - m.ior)) * n));
+    const bool inside = s >= 0.0f;   // struck from inside
+    bool hemi = false, specular = false;
+    if (!inside) {
+        const float reflection = m.diffuse + m.specular;
+        const float options = reflection + m.transmittance;
+        const float which = rng.uniform(0.0f, options);
+        hemi = which < reflection;
+        specular = hemi && !(which < m.diffuse);
+    }
+    f3 h = mk3(0.0f, 0.0f, 0.0f);
+    if (hemi) h = cosine_hemisphere(n, rng);
+    const bool diffuse = hemi && !specular;
+    f3 v = h;
+    if (!diffuse) {
+        f3 raw;
+        if (specular) {
+            const f3 sc = (1.0f - m.sharpness) * h;
+            raw = mirror(in, n) + sc;
+        } else {   // refraction, out of or into the object
+            const float k = inside ? 1.0f - m.ior : 1.0f - 1.0f / m.ior;
+            raw = in + ((s * k) * n);
+        }
+        v = unit(raw);
+    }
+    if (inside) {
         if (dot(v, n) >= 0.0f) {
             b.emitted = mk3(0.0f, 0.0f, 0.0f);
             b.attenuation = mk3(1.0f, 1.0f, 1.0f);
@@ -214,19 +241,7 @@ __device__ __forceinline__ Bounce deflect(const MaterialRec& m, f3 in, f3 n, Rng
     }
     b.emitted = mk3(m.emitted[0], m.emitted[1], m.emitted[2]);
     b.attenuation = mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
-    const float reflection = m.diffuse + m.specular;
-    const float options = reflection + m.transmittance;
-    const float which = rng.uniform(0.0f, options);
-    if (which < reflection) {
-        if (which < m.diffuse) {
-            b.dir = cosine_hemisphere(n, rng);
-        } else {
-            const f3 sc = (1.0f - m.sharpness) * cosine_hemisphere(n, rng);
-            b.dir = unit(mirror(in, n) + sc);
-        }
-    } else {
-        b.dir = unit(in + ((dot(in, n) * (1.0f - 1.0f / m.ior)) * n));
-    }
+    b.dir = v;
     return b;
 }
 
@@ -1104,6 +1119,15 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
             }
             ++k;
             state = SETUP;
+            // after the last SDF primitive the ray is done here and now, so that the lane fetches its next ray at the
+            // top of the next round instead of spending that round finding out
+            if (k == sc.n_sdf) {
+                if (improved) {
+                    pb.hit_key[slot] = best;
+                    pb.hit_pos[slot] = st4(best_pos);
+                }
+                state = IDLE;
+            }
         }
     }
     wave_add_total(&pb.totals->sdf_far_evals, c_far);
@@ -1212,14 +1236,16 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
                     const f3 ld = lin_mul(pr.inv, d);
                     const f3 lp = aff_pos(pr.inv, wp);
                     f3 nrm;
-                    if (pr.kind == 0u) {
-                        nrm = unit(lp);   // Sphere::normal src/Geometry.cpp:43-45
-                    } else if (pr.kind == 1u) {
+                    if (pr.kind == 1u) {
                         nrm = rect_normal(lp, mk3(pr.p[0], pr.p[1], pr.p[2]));
-                    } else {   // Triangle::normal src/Geometry.cpp:18-20
-                        const f3 a = mk3(pr.p[0], pr.p[1], pr.p[2]), b = mk3(pr.p[3], pr.p[4], pr.p[5]);
-                        const f3 c = mk3(sc.tri_c[3 * prim], sc.tri_c[3 * prim + 1], sc.tri_c[3 * prim + 2]);
-                        nrm = unit(cross(b - a, c - a));
+                    } else {
+                        f3 raw = lp;   // Sphere::normal src/Geometry.cpp:43-45
+                        if (pr.kind == 2u) {   // Triangle::normal src/Geometry.cpp:18-20
+                            const f3 a = mk3(pr.p[0], pr.p[1], pr.p[2]), b = mk3(pr.p[3], pr.p[4], pr.p[5]);
+                            const f3 c = mk3(sc.tri_c[3 * prim], sc.tri_c[3 * prim + 1], sc.tri_c[3 * prim + 2]);
+                            raw = cross(b - a, c - a);
+                        }
+                        nrm = unit(raw);   // one normalisation for the lanes of either kind
                     }
                     const uint32_t s_local = slot / bp.n_pix;
                     uint32_t px, py;
