@@ -21,6 +21,12 @@ namespace mipt {
 // =============================================================================================
 // exact part
 // =============================================================================================
+// Two floats that packed instructions (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32) work on at once: the same
+// IEEE operations as on single floats, two per issue slot.
+typedef float fx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fx2 fma2(fx2 a, fx2 b, fx2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ fx2 splat2(float v) { return fx2{v, v}; }
+
 struct f3 {
     float x, y, z;
 };
@@ -466,20 +472,19 @@ __device__ __forceinline__ void trav_order(float& ta, int& ca, float& tb, int& c
 // Entry distance of the ray into each of two boxes given the boxes' near and far planes per axis (already picked by
 // the sign of the ray's direction), or `far` for a box the ray misses or enters beyond `limit`.  The same arithmetic
 // as slab(), two boxes at a time so that the subtractions and multiplications are packed instructions.
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 slab_pair(f2 nx, f2 ny, f2 nz, f2 fx, f2 fy, f2 fz, f3 o, f3 inv_d, float limit, float far) {
-    const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-    const f2 ix = {inv_d.x, inv_d.x}, iy = {inv_d.y, inv_d.y}, iz = {inv_d.z, inv_d.z};
-    const f2 ax = (nx - ox) * ix, ay = (ny - oy) * iy, az = (nz - oz) * iz;
-    const f2 bx = (fx - ox) * ix, by = (fy - oy) * iy, bz = (fz - oz) * iz;
-    const f2 grow = {1.0000005f, 1.0000005f};
-    f2 tn, tf;
+__device__ __forceinline__ fx2 slab_pair(fx2 nx, fx2 ny, fx2 nz, fx2 fx, fx2 fy, fx2 fz, f3 o, f3 inv_d, float limit, float far) {
+    const fx2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const fx2 ix = {inv_d.x, inv_d.x}, iy = {inv_d.y, inv_d.y}, iz = {inv_d.z, inv_d.z};
+    const fx2 ax = (nx - ox) * ix, ay = (ny - oy) * iy, az = (nz - oz) * iz;
+    const fx2 bx = (fx - ox) * ix, by = (fy - oy) * iy, bz = (fz - oz) * iz;
+    const fx2 grow = {1.0000005f, 1.0000005f};
+    fx2 tn, tf;
     tn.x = fmaxf(fmaxf(ax.x, ay.x), fmaxf(az.x, 0.0f));
     tn.y = fmaxf(fmaxf(ax.y, ay.y), fmaxf(az.y, 0.0f));
     tf.x = fminf(fminf(bx.x, by.x), bz.x);
     tf.y = fminf(fminf(bx.y, by.y), bz.y);
     tf = tf * grow;
-    f2 r;
+    fx2 r;
     r.x = (tn.x <= tf.x && tn.x <= limit) ? tn.x : far;
     r.y = (tn.y <= tf.y && tn.y <= limit) ? tn.y : far;
     return r;
@@ -505,8 +510,8 @@ __device__ __forceinline__ void trav_inner_step(const SceneDev& sc, Trav& t, int
     // (origin and reciprocal direction as six values of their own: left grouped in threes, the compiler regroups
     // them for the packed arithmetic through memory)
     asm volatile("" : "+v"(t.o.x), "+v"(t.o.y), "+v"(t.o.z), "+v"(t.inv_d.x), "+v"(t.inv_d.y), "+v"(t.inv_d.z));
-    const f2 t01 = slab_pair(f2{nx.x, nx.y}, f2{ny.x, ny.y}, f2{nz.x, nz.y}, f2{fx.x, fx.y}, f2{fy.x, fy.y}, f2{fz.x, fz.y}, t.o, t.inv_d, t.limit, far);
-    const f2 t23 = slab_pair(f2{nx.z, nx.w}, f2{ny.z, ny.w}, f2{nz.z, nz.w}, f2{fx.z, fx.w}, f2{fy.z, fy.w}, f2{fz.z, fz.w}, t.o, t.inv_d, t.limit, far);
+    const fx2 t01 = slab_pair(fx2{nx.x, nx.y}, fx2{ny.x, ny.y}, fx2{nz.x, nz.y}, fx2{fx.x, fx.y}, fx2{fy.x, fy.y}, fx2{fz.x, fz.y}, t.o, t.inv_d, t.limit, far);
+    const fx2 t23 = slab_pair(fx2{nx.z, nx.w}, fx2{ny.z, ny.w}, fx2{nz.z, nz.w}, fx2{fx.z, fx.w}, fx2{fy.z, fy.w}, fx2{fz.z, fz.w}, t.o, t.inv_d, t.limit, far);
     float t0 = t01.x, t1 = t01.y, t2 = t23.x, t3 = t23.y;
     // a child that is not hit is ordered last and marked absent (an entry distance is far below 3.4e38:
     // limits start at 3e38)
