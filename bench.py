@@ -50,7 +50,7 @@ PEAK_HBM_GBS = 8000.0
 L2_GATHER_GBS = 17800.0
 # Algorithmic bytes of the closest-hit kernels: per ray 32 B read (origin, direction) + 24 B written (hit key, hit
 # position); per node visit one 64-byte BVH2 node (both children's boxes + links); per primitive test one 128-byte record.
-BYTES_PER_RAY, BYTES_PER_NODE, BYTES_PER_PRIM_TEST = 56, 64, 128
+BYTES_PER_RAY, BYTES_PER_NODE, BYTES_PER_PRIM_TEST = 56, 128, 128
 
 
 def parse():
@@ -306,7 +306,7 @@ def main():
                                    "work; peak = fp32 vector peak (the f32 matrix-core peak is the same 157.3)"}
     elif dominant is not None:
         # analytic scenes: one more frame with the counting build of the closest-hit kernels (outside the timed region)
-        # gives node visits and primitive tests; both closest-hit kernels together are priced as rays * 56 + nodes * 64 + tests * 128
+        # gives node visits and primitive tests; both closest-hit kernels together are priced as rays * 56 + nodes * 128 + tests * 128
         ctx.set_counting(True)
         d_sum.zero_()
         my_first, my_spp0 = shard.sample_range(frame_spp, world, rank)
@@ -327,15 +327,15 @@ def main():
                 traffic = 2.0 * (ext["FETCH_SIZE"] + gen["FETCH_SIZE"]) * 1024.0 / max(1.0, ext["dispatches"] + gen["dispatches"])
                 traffic_source = f"profiles/r02_pmc_fetch_{prof}.csv: 2 x FETCH_SIZE KB per launch (reads that go past L2; wide reads corrected x2)"
         out["roofline"] = {"kernel": "k_generate_extend + k_extend (closest hit)", "bound": "hbm",
-                           "bound_detail": "gather of 64-B nodes and 128-B primitive records, served mostly from L2 / Infinity Cache; measured limiter: vector issue at partial lane occupancy",
+                           "bound_detail": "gather of 128-B four-child nodes and 128-B primitive records, served mostly from L2 / Infinity Cache; measured limiter: vector issue at partial lane occupancy",
                            "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                            "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_source,
                            "avg_launch_ms": trav_ms / n_launch, "launches": n_launch,
                            "l2_gather_peak": L2_GATHER_GBS, "frac_of_l2_gather": achieved / L2_GATHER_GBS,
                            "node_visits_per_ray": cst["node_visits"] / max(1, cst["rays"]), "prim_tests_per_ray": cst["prim_tests"] / max(1, cst["rays"]),
                            "bytes_per_ray": bytes_alg / max(1, cst["rays"]),
-                           "note": "bytes = rays*56 + node_visits*64 + prim_tests*128 per frame (counting build, one extra frame outside the timed region) over "
-                                   "the frame's closest-hit kernel time (HIP events); the tree (6.4 MB of nodes + 12.8 MB of records at 100k objects) "
+                           "note": "bytes = rays*56 + node_visits*128 + prim_tests*128 per frame (counting build, one extra frame outside the timed region) over "
+                                   "the frame's closest-hit kernel time (HIP events); the tree (6.5 MB of nodes + 12.8 MB of records at 100k objects) "
                                    "fits the caches, so algorithmic bytes per second exceed what HBM moves (frac > 1 against the HBM peak); "
                                    "frac_of_l2_gather prices the same bytes against the chip's L2 gather rate"}
 

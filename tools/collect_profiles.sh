@@ -30,6 +30,7 @@ stats demo1080p --steps 3 --warmup 1
 pmc sq_demo1080p_1024spp SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU --
 pmc fetch_demo1080p_1024spp FETCH_SIZE --
 pmc write_demo1080p_1024spp WRITE_SIZE --
+python3 $R/tools/merge_hbm.py $OUT/r02_pmc_fetch_demo1080p_1024spp.csv $OUT/r02_pmc_write_demo1080p_1024spp.csv $OUT/r02_pmc_hbm_demo1080p_1024spp.csv
 pmc mfma_demo1080p_1024spp SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES --
 for sc in random100k mixed20k random1m; do
   case $sc in
