@@ -55,6 +55,7 @@ struct mipt_ctx {
     bool device_bvh = false;        // MIPT_DEVICE_BVH=1: mipt_scene_upload builds the tree on the GPU
     bool full_march = false;        // MIPT_FULL_MARCH=1: no shortcut for SDF marches that cannot end (for the equivalence test)
     uint32_t lane_threshold = 14;   // MIPT_LANE_THRESHOLD: 1 = always one point per lane, 65 = never
+    int min_stack = 0;   // MIPT_MIN_STACK: the traversal kernels are picked as if every tree needed at least this many stack entries (a test aid)
     uint32_t trav_quorum = 20, trav_quorum_primary = 2, trav_keep = 40;   // MIPT_LEAF_QUORUM, MIPT_LEAF_QUORUM_PRIMARY, MIPT_KEEP_BUSY: scheduling of the BVH traversal's two phases (tuning aids)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -472,7 +473,7 @@ int enqueue_bounces(mipt_ctx* c, const mipt_scene* sc, const BatchParams& bp, ui
     for (uint32_t b = 0; b < bounces; ++b) {
         const int done = b == 0 ? first_done : 0;
         if (b > 0) launch_latch_cancel(c->stream, c->pb);
-        if (done < 1) { StageTimer t(c, MIPT_STAGE_EXTEND); launch_extend(c->stream, sc->dev, bp, c->pb, b, sc->stack_need, c->counting); }
+        if (done < 1) { StageTimer t(c, MIPT_STAGE_EXTEND); launch_extend(c->stream, sc->dev, bp, c->pb, b, std::max(sc->stack_need, c->min_stack), c->counting); }
         if (sc->n_sdf && done < 2) { StageTimer t(c, MIPT_STAGE_SDF_MARCH); launch_sdf_march(c->stream, sc->dev, bp, c->pb, b); }
         if (host && done < 3) {
             const int rc = host_objects_extend(c, sc, b, ht);
@@ -621,7 +622,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
         launch_latch_cancel(c->stream, c->pb);
-        { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate_extend(c->stream, cr, sc->dev, bp, c->pb, cull, sc->stack_need, c->counting); }
+        { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate_extend(c->stream, cr, sc->dev, bp, c->pb, cull, std::max(sc->stack_need, c->min_stack), c->counting); }
         if (const int rb = enqueue_bounces(c, sc, bp, st->bounces, 1, &host_totals); rb != MIPT_OK) return rb;
         launch_latch_cancel(c->stream, c->pb);
         { StageTimer t(c, MIPT_STAGE_ACCUMULATE); launch_accumulate(c->stream, bp, c->pb, d_sum); }
@@ -724,6 +725,7 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
     if (const char* e = std::getenv("MIPT_DEVICE_BVH")) c->device_bvh = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_LEAF_QUORUM")) c->trav_quorum = static_cast<uint32_t>(std::min(64L, std::max(1L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_LEAF_QUORUM_PRIMARY")) c->trav_quorum_primary = static_cast<uint32_t>(std::min(64L, std::max(1L, std::atol(e))));
+    if (const char* e = std::getenv("MIPT_MIN_STACK")) c->min_stack = static_cast<int>(std::min(long(kMaxTraversalStack), std::max(0L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_KEEP_BUSY")) c->trav_keep = static_cast<uint32_t>(std::min(64L, std::max(0L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_LANE_THRESHOLD")) {
         const long v = std::atol(e);
@@ -1296,7 +1298,7 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->pb.hit_key, 0xff, n * 8, c->stream));   // the fused kernel stores hits only
     launch_latch_cancel(c->stream, c->pb);
-    launch_generate_extend(c->stream, pack_camera(c0), sc->dev, bp, c->pb, screen_rects(sc, c0, width, height), sc->stack_need);
+    launch_generate_extend(c->stream, pack_camera(c0), sc->dev, bp, c->pb, screen_rects(sc, c0, width, height), std::max(sc->stack_need, c->min_stack));
     if (sc->n_sdf) launch_sdf_march(c->stream, sc->dev, bp, c->pb, 0);
     if (!sc->host_prims.empty()) {
         Totals unused{};
@@ -1353,7 +1355,7 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     std::vector<unsigned long long> keys;
     if (out_first_prim || out_first_t) {
         // first closest hit, before shading overwrites the rays
-        launch_extend(c->stream, sc->dev, bp, c->pb, 0, sc->stack_need);
+        launch_extend(c->stream, sc->dev, bp, c->pb, 0, std::max(sc->stack_need, c->min_stack));
         if (sc->n_sdf) launch_sdf_march(c->stream, sc->dev, bp, c->pb, 0);
         if (!sc->host_prims.empty()) {
             Totals unused{};

@@ -80,6 +80,64 @@ def test_coincident_and_degenerate_boxes(ctx, alg, oracle):
     assert (want_prim >= 0).any()
 
 
+def test_deep_trees_walk_with_the_deep_stacks(ctx, alg, oracle):
+    """Spheres whose centres and radii grow geometrically: the surface-area heuristic peels them off one or two at a time, the
+    tree is a chain, and the traversal runs in its instantiations with the deepest stacks.  First hits and 6-bounce radiance
+    against the oracle's scan, for both builders."""
+    n = 58
+    flat = S.random_scene(alg, n, seed=2, radius_scale=1.0)
+    flat.kind[:] = S.SPHERE
+    x = (1.5 ** np.arange(n)).astype(np.float32)
+    flat.fwd[:] = 0.0
+    flat.fwd[:, 0] = flat.fwd[:, 4] = flat.fwd[:, 8] = 1.0
+    flat.fwd[:, 9] = x
+    flat.params[:] = 0.0
+    flat.params[:, 0] = 0.2 * x
+    flat.inv[:] = alg.affine_inverse_batch(flat.fwd)
+    r = np.random.RandomState(3)
+    i = r.randint(0, n, 4096)
+    c = np.zeros((4096, 3), np.float32)
+    c[:, 0] = x[i]
+    rad = (0.2 * x[i])[:, None].astype(np.float32)
+    away = r.normal(size=(4096, 3)).astype(np.float32)
+    away /= np.linalg.norm(away, axis=1, keepdims=True)
+    o = (c + 3.0 * rad * away).astype(np.float32)
+    target = (c + 0.7 * rad * r.uniform(-1, 1, (4096, 3))).astype(np.float32)
+    d = (target - o).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    osc = oracle.scene(flat)
+    wp, wt, _ = osc.closest_hit(o, d)
+    want = osc.trace(o, d, 6, rng_mode=1, seed=8)
+    depths = []
+    for dev_build in (False, True):
+        ds = ctx.upload(flat, device_bvh=dev_build)
+        depths.append(ds.info()["depth"])
+        got, prim, t = ctx.trace_rays(ds, o, d, 6, seed=8, first_hit=True)
+        assert np.array_equal(wp, prim) and np.array_equal(wt[wp >= 0], t[wp >= 0])
+        close = np.all(np.abs(want - got) <= 1e-4 * np.maximum(1.0, np.abs(want)), axis=1)
+        assert close.mean() >= 0.995, close.mean()
+    print(f"chain of {n} spheres: tree depth {depths[0]} (host build), {depths[1]} (device build)")
+    assert (wp >= 0).mean() > 0.8
+    # every instantiation of the traversal kernels (stacks of 8, 24, 32, 48 and 60 entries) on one scene: identical frames
+    flat = S.random_scene(alg, 40, seed=4, radius_scale=12.0, glass_mirror_mix=True)
+    cam = S.random_scene_camera(alg, aspect=1.0)
+    frames = []
+    for need in ("0", "20", "30", "40", "60"):
+        os.environ["MIPT_MIN_STACK"] = need
+        try:
+            c = api.Context()
+        finally:
+            os.environ.pop("MIPT_MIN_STACK", None)
+        try:
+            img, st = c.render(c.upload(flat), cam, 96, 96, 8, 8, seed=6)
+            frames.append((img, st["rays"]))
+        finally:
+            c.close()
+    for img, rays in frames[1:]:
+        assert np.array_equal(img, frames[0][0]) and rays == frames[0][1]
+    assert frames[0][0].max() > 0
+
+
 def test_100k_primitives_device_build_is_fast_and_exact(ctx, alg, oracle):
     flat = S.random_scene(alg, 100_000, seed=7)
     cam = S.random_scene_camera(alg)

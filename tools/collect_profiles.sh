@@ -32,6 +32,9 @@ pmc fetch_demo1080p_1024spp FETCH_SIZE --
 pmc write_demo1080p_1024spp WRITE_SIZE --
 python3 $R/tools/merge_hbm.py $OUT/r02_pmc_fetch_demo1080p_1024spp.csv $OUT/r02_pmc_write_demo1080p_1024spp.csv $OUT/r02_pmc_hbm_demo1080p_1024spp.csv
 pmc mfma_demo1080p_1024spp SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES --
+# the bench lines quote the counter passes: the lines of this collection have to read this collection's passes
+bench_reads() { cp "$@" $R/profiles/; }
+bench_reads $OUT/r02_pmc_sq_demo1080p_1024spp.csv $OUT/r02_pmc_hbm_demo1080p_1024spp.csv
 for sc in random100k mixed20k random1m; do
   case $sc in
     random100k) A="--scene random100k --spp 256"; N=random100k_256spp;;
@@ -41,6 +44,7 @@ for sc in random100k mixed20k random1m; do
   pmc sq_$N SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU -- $A
   pmc cache_$N TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum -- $A
   pmc fetch_$N FETCH_SIZE -- $A
+  bench_reads $OUT/r02_pmc_fetch_$N.csv
   timeout -k 10 400 python3 $R/bench.py $A --steps 3 --warmup 1 > $OUT/r02_bench_$N.json 2> /tmp/bench_$N.err
   echo "bench $N done"
 done
