@@ -938,6 +938,8 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
     Bvh4Result bvh4 = collapse_bvh4(bvh.nodes.data(), bvh.nodes.size(), n);
     // the deepest traversal stack the kernels carry; only a great many coincident boxes get there
     if (bvh.depth > 60 || bvh4.stack_need > kMaxTraversalStack) return MIPT_ERR_TOO_LARGE;
+    // the traversal addresses a node by a 32-bit byte offset (index * 128)
+    if (bvh4.nodes.size() > (size_t(1) << 25)) return MIPT_ERR_TOO_LARGE;
 
     // Big craters of each crater ball (for_each_nearby_scattered_point at scale 2, PathTracerDemo.cpp:375-409):
     // which lattice cells pass the shell test depends on the ball's offset alone.  The device evaluates the

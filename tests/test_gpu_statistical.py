@@ -56,3 +56,42 @@ def test_converged_image_matches_reference_renderer(name):
     rel = np.abs(_box(fine) - ref_mean).mean() / ref_mean.mean()
     assert rel <= 0.02, rel
     assert abs(float(fine.mean()) / float(ref_mean.mean()) - 1.0) <= 0.01
+
+
+def test_demo_view_at_1080p_against_the_cpu_restatement(oracle):
+    """The headline frame's own view (not the close-up), 1920 x 1080, 16 spp on both sides: GPU against the CPU restatement of
+    the reference renderer (reference random numbers, two seeds) on the 256 x 256 crop around the ball.  Accepted as the
+    bench line's `rmse` object is: RMSE within 1.25 x the CPU's own seed-to-seed RMSE, the 8 x 8 box-filtered relative error
+    within 1.25 x of what two CPU seeds show, crop means within 2 %."""
+    from oracle import orc
+    z = np.load(FIXTURE, allow_pickle=False)
+    alg = api.HostAlgebra()
+    flat = S.demo_scene(alg, z["noise12"])
+    cam = S.demo_camera(alg)
+    W, H, bounces, spp = 1920, 1080, 8, 16
+    osc = oracle.scene(flat)
+    cpu_a, _ = osc.render(cam, W, H, bounces, spp, rng_mode=orc.RNG_MINSTD, seed=1, threads=16, full_width=False)
+    cpu_b, _ = osc.render(cam, W, H, bounces, spp, rng_mode=orc.RNG_MINSTD, seed=2, threads=16, full_width=False)
+    ctx = api.Context()
+    gpu, st = ctx.render(ctx.upload(flat), cam, W, H, bounces, spp, seed=77)
+    ctx.close()
+    ys, xs = np.nonzero((cpu_a + cpu_b).sum(axis=2) > 0)
+    cy, cx = int(round(ys.mean())), int(round(xs.mean()))
+    y0, x0 = max(0, min(H - 256, cy - 128)), max(0, min(W - 256, cx - 128))
+    crop = (slice(y0, y0 + 256), slice(x0, x0 + 256))
+    ga, ca, cb = (x[crop].astype(np.float64) for x in (gpu, cpu_a, cpu_b))
+    rmse = lambda p, q: float(np.sqrt(np.mean((p - q) ** 2)))
+
+    def box_rel(p, q):
+        bp, bq = _box(p).mean(axis=2), _box(q).mean(axis=2)
+        m = bq > 0.05 * bq.max()
+        return float(np.mean(np.abs(bp[m] - bq[m]) / bq[m]))
+
+    floor, got = rmse(ca, cb), rmse(ga, ca)
+    print(f"demo view 1080p, {spp} spp, crop at ({x0}, {y0}): RMSE GPU-CPU {got:.5f}, CPU-CPU {floor:.5f}; box-filtered relative error "
+          f"{box_rel(ga, ca):.4f} against {box_rel(cb, ca):.4f}; means {ga.mean():.5f} / {ca.mean():.5f}")
+    assert floor > 0 and got <= 1.25 * floor
+    assert box_rel(ga, ca) <= 1.25 * box_rel(cb, ca)
+    assert abs(ga.mean() / (0.5 * (ca.mean() + cb.mean())) - 1.0) <= 0.02
+    # outside the crop's object nothing is lit on either side
+    assert st["paths"] == W * H * spp
