@@ -407,12 +407,14 @@ __device__ __forceinline__ void coop_near(const CoopLane& cl, float* lds, float4
     f3 ur = u[0], offr = off[0];
     uint32_t min_age_r = min_age0[0];
 #pragma unroll
-    for (int g = 1; g < G; ++g)
-        if (row == static_cast<uint32_t>(g)) {
-            ur = u[g];
-            offr = off[g];
-            min_age_r = min_age0[g];
-        }
+    for (int g = 1; g < G; ++g) {
+        const bool mine = row == static_cast<uint32_t>(g);
+        ur = mk3(mine ? u[g].x : ur.x, mine ? u[g].y : ur.y, mine ? u[g].z : ur.z);
+        offr = mk3(mine ? off[g].x : offr.x, mine ? off[g].y : offr.y, mine ? off[g].z : offr.z);
+        min_age_r = mine ? min_age0[g] : min_age_r;
+        // (kept a chain of selects: read as an array indexed by the row, `u` moves to scratch memory)
+        asm volatile("" : "+v"(ur.x), "+v"(ur.y), "+v"(ur.z));
+    }
     const bool in_use = row < static_cast<uint32_t>(G);
     const bool tiny_lane = (lane & 8u) != 0u;
     const float scale = tiny_lane ? 60.0f : 10.0f;
