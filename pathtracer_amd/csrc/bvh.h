@@ -1,7 +1,8 @@
-// Host BVH builder: binned surface-area heuristic over primitive world boxes, emitted as the
-// linear two-child node array the extend kernel walks.  It replaces ObjectTree::Tree::makeTree
-// (src/ObjectTree.cpp:90-184), whose cost grows like N^2.6; because the reference's tree never
-// culls, every topology returns the same closest hit.
+// Host BVH builder: binned surface-area heuristic over primitive world boxes, emitted as a linear
+// two-child node array, and the collapse of such an array (this builder's or the device builder's)
+// into the four-child nodes the closest-hit kernels walk.  Together they replace
+// ObjectTree::Tree::makeTree (src/ObjectTree.cpp:90-184), whose cost grows like N^2.6; because the
+// reference's tree never culls, every topology returns the same closest hit.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
