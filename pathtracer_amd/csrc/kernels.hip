@@ -1190,14 +1190,20 @@ __device__ __forceinline__ bool apply_bounce(const PathBuffers& pb, uint32_t slo
     const f3 npos = mk3(world_pos.x + 1e-3f * wdir.x, world_pos.y + 1e-3f * wdir.y, world_pos.z + 1e-3f * wdir.z);   // src/Scene.cpp:54
     // a path starts with attenuation 1 and no radiance (src/Scene.cpp:19-20); neither is stored before the first hit
     float4 att = bounce == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : pb.att[slot];
-    float4 rad = bounce == 0 ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : pb.rad[slot];
-    rad.x += b.emitted.x * att.x;
-    rad.y += b.emitted.y * att.y;
-    rad.z += b.emitted.z * att.z;
+    // radiance += emitted * attenuation (src/Scene.cpp:56-58).  Most surfaces emit nothing: the sum then keeps its bits
+    // (x + 0 * a = x for finite a; the sum starts at +0 and never becomes -0), and its 32 bytes of traffic are left out.
+    const bool lit = b.emitted.x != 0.0f || b.emitted.y != 0.0f || b.emitted.z != 0.0f;
+    const float att_sum = att.x + att.y + att.z;
+    if (lit || !(fabsf(att_sum) <= 3.402823466e38f)) {
+        float4 rad = bounce == 0 ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : pb.rad[slot];
+        rad.x += b.emitted.x * att.x;
+        rad.y += b.emitted.y * att.y;
+        rad.z += b.emitted.z * att.z;
+        pb.rad[slot] = rad;
+    }
     att.x *= b.attenuation.x;
     att.y *= b.attenuation.y;
     att.z *= b.attenuation.z;
-    pb.rad[slot] = rad;
     const bool alive = !(att.x + att.z + att.y < 1e-6f) && (bounce + 1 < max_bounces);   // r + b + g, src/Scene.cpp:73
     if (alive) {
         pb.att[slot] = att;
