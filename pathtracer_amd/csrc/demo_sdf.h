@@ -39,12 +39,24 @@ __device__ __forceinline__ VoronoiHit voronoi_general(f3 location, float half_sc
                               (0.0f * location.x + 0.0f * location.y) + 1.0f * location.z);
     VoronoiHit v{3.402823466e38f, 3.402823466e38f, 0u};
     const f3 origin = mk3(floorf(location.x), floorf(location.y), floorf(location.z));
+    // the hash of a cell starts from a sum that is linear in its lattice coordinates (mod 2^32): one seed for the
+    // origin's cell, constant steps to its neighbours
+    const uint32_t seed0 = cell_hash_seed(origin);
     for (int i = -1; i <= 2; ++i)
         for (int j = -1; j <= 2; ++j)
 #pragma unroll
             for (int k = -1; k <= 2; ++k) {
-                uint32_t h;
-                const f3 c = scattered_cell(origin + mk3(static_cast<float>(i), static_cast<float>(j), static_cast<float>(k)), half_scatter, h);
+                const uint32_t h = cell_hash_mix(seed0 + static_cast<uint32_t>(i * kHashX + j * kHashY + k * kHashZ));
+                const f3 g = origin + mk3(static_cast<float>(i), static_cast<float>(j), static_cast<float>(k));
+                f3 c;   // scattered_cell's point
+                if (SHEAR) {
+                    const float mx = fmaf(static_cast<float>(h & 0x3ffu), 1.0f / 512.0f, -1.0f);
+                    const float my = fmaf(static_cast<float>((h >> 10) & 0x3ffu), 1.0f / 512.0f, -1.0f);
+                    const float mz = fmaf(static_cast<float>((h >> 20) & 0x3ffu), 1.0f / 512.0f, -1.0f);
+                    c = mk3(fmaf(half_scatter, mx, g.x), fmaf(half_scatter, my, g.y), fmaf(half_scatter, mz, g.z));
+                } else {
+                    c = jitter_unit(mk3(g.x - 0.5f, g.y - 0.5f, g.z - 0.5f), h);   // scatter 1: the same value with one rounding, see jitter_unit
+                }
                 f3 q = location - c;
                 if (SHEAR) q = mk3((1.0f * q.x + 0.5f * q.y) + 0.0f * q.z, (0.0f * q.x + 0.5f * q.y) + 0.0f * q.z, (0.0f * q.x + 0.0f * q.y) + 1.0f * q.z);
                 const float d = norm_sq(q);
@@ -58,6 +70,7 @@ __device__ __forceinline__ VoronoiHit voronoi_general(f3 location, float half_sc
             }
     return v;
 }
+// (the plain form is only ever used with scatter 1: its cells' points come from jitter_unit)
 __device__ __forceinline__ VoronoiHit voronoi_cells(f3 location) { return voronoi_general<false>(location, 0.5f); }
 
 __device__ __forceinline__ float rect_sdf(f3 half, f3 p) {   // Rectangle::signedDistance src/Geometry.cpp:66-75
