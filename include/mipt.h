@@ -133,6 +133,13 @@ typedef struct {
     /* The slow path of scenes with MIPT_HOST_OBJECT primitives: Object::hitRay and Object::deflectRay calls made on the host. */
     uint64_t host_rays;
     uint64_t host_shades;
+    /* Also from the counting build, for the closest-hit kernels of the bounces after the first: rounds of the wave
+     * state machine (one node visit per lane that can take one), leaf steps among them (Object::hitRay for every lane
+     * with a pending leaf), and the times the second ray of a lane started over because the first needed their shared
+     * stack column.  node_visits / (64 trav_rounds) is the share of lanes at work in a round. */
+    uint64_t trav_rounds;
+    uint64_t trav_leaf_steps;
+    uint64_t trav_restarts;
 } mipt_stats;
 
 enum { MIPT_STAGE_GENERATE = 0, MIPT_STAGE_EXTEND = 1, MIPT_STAGE_SDF_MARCH = 2, MIPT_STAGE_SHADE = 3,

@@ -56,6 +56,8 @@ struct mipt_ctx {
     bool full_march = false;        // MIPT_FULL_MARCH=1: no shortcut for SDF marches that cannot end (for the equivalence test)
     uint32_t lane_threshold = 14;   // MIPT_LANE_THRESHOLD: 1 = always one point per lane, 65 = never
     int min_stack = 0;   // MIPT_MIN_STACK: the traversal kernels are picked as if every tree needed at least this many stack entries (a test aid)
+    bool pair_tight = false;   // MIPT_PAIR_TIGHT=1 (test aid): the two rays of a lane share only as many stack rows as one ray can need (+ 3), so the second ray starts over often
+    uint32_t trav_quorum_pair = 32, trav_keep_pair = 76;   // MIPT_PAIR_QUORUM (0: one ray per lane), MIPT_PAIR_KEEP: the same with two rays per lane
     uint32_t trav_quorum = 20, trav_quorum_primary = 2, trav_keep = 40;   // MIPT_LEAF_QUORUM, MIPT_LEAF_QUORUM_PRIMARY, MIPT_KEEP_BUSY: scheduling of the BVH traversal's two phases (tuning aids)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -619,6 +621,9 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
     bp.trav_quorum = c->trav_quorum;
     bp.trav_quorum_primary = c->trav_quorum_primary;
     bp.trav_keep = c->trav_keep;
+    bp.trav_quorum_pair = c->trav_quorum_pair;
+    bp.trav_keep_pair = c->trav_keep_pair;
+    bp.pair_rows = c->pair_tight ? static_cast<uint32_t>(std::max(sc->stack_need, c->min_stack)) + 3u : 0u;
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
         launch_latch_cancel(c->stream, c->pb);
@@ -653,6 +658,9 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         stats->samples_done = t.samples_done;
         stats->node_visits = t.node_visits;
         stats->prim_tests = t.prim_tests;
+        stats->trav_rounds = t.trav_rounds;
+        stats->trav_leaf_steps = t.trav_leaf_steps;
+        stats->trav_restarts = t.trav_restarts;
         stats->host_rays = host_totals.host_rays;
         stats->host_shades = host_totals.host_shades;
         stats->ms_device = ms;
@@ -726,6 +734,9 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
     if (const char* e = std::getenv("MIPT_LEAF_QUORUM")) c->trav_quorum = static_cast<uint32_t>(std::min(64L, std::max(1L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_LEAF_QUORUM_PRIMARY")) c->trav_quorum_primary = static_cast<uint32_t>(std::min(64L, std::max(1L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_MIN_STACK")) c->min_stack = static_cast<int>(std::min(long(kMaxTraversalStack), std::max(0L, std::atol(e))));
+    if (const char* e = std::getenv("MIPT_PAIR_QUORUM")) c->trav_quorum_pair = static_cast<uint32_t>(std::min(64L, std::max(0L, std::atol(e))));
+    if (const char* e = std::getenv("MIPT_PAIR_TIGHT")) c->pair_tight = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_PAIR_KEEP")) c->trav_keep_pair = static_cast<uint32_t>(std::min(128L, std::max(0L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_KEEP_BUSY")) c->trav_keep = static_cast<uint32_t>(std::min(64L, std::max(0L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_LANE_THRESHOLD")) {
         const long v = std::atol(e);
@@ -1018,7 +1029,25 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
     hipError_t e = upload(&s->d_prims, prims.data(), prims.size() * sizeof(PrimRec));
     if (e == hipSuccess) e = upload(&s->d_tri, tri_c.data(), tri_c.size() * sizeof(float));
     if (e == hipSuccess) e = upload(&s->d_mats, mats.data(), mats.size() * sizeof(MaterialRec));
-    if (e == hipSuccess) e = upload(&s->d_nodes, bvh4.nodes.data(), bvh4.nodes.size() * sizeof(Bvh4Node));
+    std::vector<Bvh4QNode> qnodes = quantize_bvh4(bvh4.nodes);   // the 64-byte form the kernels read
+    if (const char* nc = std::getenv("MIPT_NO_CULL"); nc && std::atoi(nc) != 0) {
+        // test aid: every box of the tree becomes all of space, so that every ray visits every node and tests every
+        // primitive -- the reference's own rule (src/ObjectTree.cpp:22-88 never culls) through the same kernels; a frame
+        // must not depend on it
+        for (Bvh4QNode& n : qnodes)
+            for (int a = 0; a < 3; ++a) {
+                n.org[a] = -1e18f;
+                n.scale[a] = 1e16f;
+                n.qlo[a] = 0u;
+                n.qhi[a] = 0xffffffffu;
+            }
+        for (size_t i = 0; i + 7 < bvh4.leaf_boxes.size(); i += 8)
+            for (int a = 0; a < 3; ++a) {
+                bvh4.leaf_boxes[i + a] = -1e18f;
+                bvh4.leaf_boxes[i + 4 + a] = 1e18f;
+            }
+    }
+    if (e == hipSuccess) e = upload(&s->d_nodes, qnodes.data(), qnodes.size() * sizeof(Bvh4QNode));
     if (e == hipSuccess && !bvh4.nodes.empty()) e = upload(&s->d_leaf_boxes, bvh4.leaf_boxes.data(), bvh4.leaf_boxes.size() * sizeof(float));
     if (e == hipSuccess) e = upload(&s->d_sdf, sdf.data(), sdf.size() * sizeof(SdfBox));
     if (e == hipSuccess) e = upload(&s->d_host_boxes, host_boxes.data(), host_boxes.size() * sizeof(SdfBox));
@@ -1060,7 +1089,7 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
     s->dev.prims = static_cast<const PrimRec*>(s->d_prims);
     s->dev.tri_c = static_cast<const float*>(s->d_tri);
     s->dev.materials = static_cast<const MaterialRec*>(s->d_mats);
-    s->dev.nodes = static_cast<const Bvh4Node*>(s->d_nodes);
+    s->dev.nodes = static_cast<const Bvh4QNode*>(s->d_nodes);
     s->dev.leaf_boxes = static_cast<const float*>(s->d_leaf_boxes);
     s->dev.sdf_boxes = static_cast<const SdfBox*>(s->d_sdf);
     s->dev.noise_oct = static_cast<const float*>(s->d_oct);
@@ -1295,6 +1324,9 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     bp.trav_quorum = c->trav_quorum;
     bp.trav_quorum_primary = c->trav_quorum_primary;
     bp.trav_keep = c->trav_keep;
+    bp.trav_quorum_pair = c->trav_quorum_pair;
+    bp.trav_keep_pair = c->trav_keep_pair;
+    bp.pair_rows = c->pair_tight ? static_cast<uint32_t>(std::max(sc->stack_need, c->min_stack)) + 3u : 0u;
     mipt_camera c0 = *cam;
     c0.blur_radius = 0.0f;
     HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
@@ -1349,6 +1381,9 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     bp.trav_quorum = c->trav_quorum;
     bp.trav_quorum_primary = c->trav_quorum_primary;
     bp.trav_keep = c->trav_keep;
+    bp.trav_quorum_pair = c->trav_quorum_pair;
+    bp.trav_keep_pair = c->trav_keep_pair;
+    bp.pair_rows = c->pair_tight ? static_cast<uint32_t>(std::max(sc->stack_need, c->min_stack)) + 3u : 0u;
     bp.flags = c->full_march ? kFlagFullMarch : 0u;
     bp.seed = seed;
     HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));

@@ -280,4 +280,51 @@ Bvh4Result collapse_bvh4(const BvhNode* nodes2, size_t n_nodes2, uint32_t n_prim
     return r;
 }
 
+float bvh4q_plane(const Bvh4QNode& n, int axis, uint32_t q) { return std::fmaf(static_cast<float>(q), n.scale[axis], n.org[axis]); }
+
+std::vector<Bvh4QNode> quantize_bvh4(const std::vector<Bvh4Node>& nodes) {
+    std::vector<Bvh4QNode> out(nodes.size());
+    const float inf = std::numeric_limits<float>::infinity();
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        const Bvh4Node& n = nodes[i];
+        Bvh4QNode& q = out[i];
+        const float* lo[3] = {n.lox, n.loy, n.loz};
+        const float* hi[3] = {n.hix, n.hiy, n.hiz};
+        for (int a = 0; a < 3; ++a) {
+            float mn = inf, mx = -inf;
+            for (int k = 0; k < 4; ++k)
+                if (n.child[k] != kBvh4Absent) {
+                    mn = std::min(mn, lo[a][k]);
+                    mx = std::max(mx, hi[a][k]);
+                }
+            if (!(mn <= mx)) mn = mx = 0.0f;   // a node without children (the root of an empty tree)
+            // 253 steps span the node, so that one step can be given away below every low plane and above every high one
+            float scale = std::nextafter((mx - mn) / 253.0f, inf);
+            if (!(scale >= 1e-30f)) scale = 1e-30f;
+            q.org[a] = mn;
+            q.scale[a] = scale;
+            uint32_t wlo = 0, whi = 0;
+            for (int k = 0; k < 4; ++k) {
+                uint32_t ql = 255u, qh = 0u;
+                if (n.child[k] != kBvh4Absent) {
+                    const double sl = (static_cast<double>(lo[a][k]) - mn) / scale, sh = (static_cast<double>(hi[a][k]) - mn) / scale;
+                    long l = static_cast<long>(std::floor(sl)) - 1, h = static_cast<long>(std::ceil(sh)) + 1;
+                    l = std::min(255L, std::max(0L, l));
+                    h = std::min(255L, std::max(0L, h));
+                    ql = static_cast<uint32_t>(l);
+                    qh = static_cast<uint32_t>(h);
+                    while (ql > 0 && !(bvh4q_plane(q, a, ql) <= lo[a][k])) --ql;
+                    while (qh < 255 && !(bvh4q_plane(q, a, qh) >= hi[a][k])) ++qh;
+                }
+                wlo |= ql << (8 * k);
+                whi |= qh << (8 * k);
+            }
+            q.qlo[a] = wlo;
+            q.qhi[a] = whi;
+        }
+        for (int k = 0; k < 4; ++k) q.child[k] = n.child[k];
+    }
+    return out;
+}
+
 }   // namespace mipt

@@ -38,4 +38,9 @@ struct Bvh4Result {
 };
 Bvh4Result collapse_bvh4(const BvhNode* nodes2, size_t n_nodes2, uint32_t n_prims);
 
+// The 64-byte form of the four-child nodes (same indices, same links): every decoded child box contains the original.
+std::vector<Bvh4QNode> quantize_bvh4(const std::vector<Bvh4Node>& nodes);
+// plane = org + scale * q as the quantiser guarantees it (one fused multiply-add)
+float bvh4q_plane(const Bvh4QNode& n, int axis, uint32_t q);
+
 }   // namespace mipt

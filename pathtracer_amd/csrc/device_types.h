@@ -48,6 +48,21 @@ struct alignas(128) Bvh4Node {
 static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
 constexpr int32_t kBvh4Absent = INT32_MIN;
 
+// The same node in 64 bytes, the form the kernels read: the children's boxes as 8-bit offsets from the node's own low
+// corner, in steps of `scale` per axis -- plane = org + scale * q, the low planes rounded down and the high planes up
+// (one step to spare each), so a decoded box always contains the child's.  Byte c of a word belongs to child c; an
+// absent child has low offset 255 and high offset 0.  A visit reads four 16-byte pieces instead of seven: the
+// traversal is bound by the vector-memory pipeline (address and tag processing per load instruction and lane), not by
+// arithmetic, and the looser boxes cost a few per cent more visits.
+struct alignas(64) Bvh4QNode {
+    float org[3];
+    float scale[3];
+    uint32_t qlo[3];   // x, y, z
+    uint32_t qhi[3];
+    int32_t child[4];
+};
+static_assert(sizeof(Bvh4QNode) == 64, "Bvh4QNode must be 64 bytes");
+
 // World box of one SDF primitive (tested by every ray after the analytic traversal).
 struct SdfBox {
     float lo[3];
@@ -66,7 +81,7 @@ struct SceneDev {
     const PrimRec* prims;
     const float* tri_c;            // 3 floats per primitive, only read for triangles (may be null)
     const MaterialRec* materials;
-    const Bvh4Node* nodes;         // null when the scene has no analytic primitive
+    const Bvh4QNode* nodes;        // null when the scene has no analytic primitive
     // world box of every analytic primitive as its BVH leaf holds it, 8 floats {lo.xyz, -, hi.xyz, -} at 8 * prim: lets
     // a leaf that waited on a traversal stack be tested against the limit the ray has reached since
     const float* leaf_boxes;
@@ -111,6 +126,7 @@ struct Totals {
     unsigned long long primary_traced;                                   // primary rays that were traced rather than culled on screen
     unsigned long long node_visits, prim_tests;                          // counting build of the traversal only
     unsigned long long host_rays, host_shades;                           // work handed to the host for objects without a device form
+    unsigned long long trav_rounds, trav_leaf_steps, trav_restarts;     // counting build of k_extend_pair: wave rounds, leaf steps, second rays started over
     unsigned long long samples_done;                                     // samples per pixel that entered the frame (batches accumulated before a cancel)
 };
 

@@ -469,15 +469,11 @@ __device__ __forceinline__ void trav_order(float& ta, int& ca, float& tb, int& c
     cb = ch;
 }
 
-// Entry distance of the ray into each of two boxes given the boxes' near and far planes per axis (already picked by
-// the sign of the ray's direction), or `far` for a box the ray misses or enters beyond `limit`.  The same arithmetic
-// as slab(), two boxes at a time so that the subtractions and multiplications are packed instructions.
-__device__ __forceinline__ fx2 slab_pair(fx2 nx, fx2 ny, fx2 nz, fx2 fx, fx2 fy, fx2 fz, f3 o, f3 inv_d, float limit, float far) {
-    const fx2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-    const fx2 ix = {inv_d.x, inv_d.x}, iy = {inv_d.y, inv_d.y}, iz = {inv_d.z, inv_d.z};
-    const fx2 ax = (nx - ox) * ix, ay = (ny - oy) * iy, az = (nz - oz) * iz;
-    const fx2 bx = (fx - ox) * ix, by = (fy - oy) * iy, bz = (fz - oz) * iz;
-    const fx2 grow = {1.0000005f, 1.0000005f};
+// Entry distance of the ray into each of two boxes given the ray parameters at which it crosses the boxes' near (a)
+// and far (b) planes per axis, or `far` for a box the ray misses or enters beyond `limit`.  The same decision as
+// slab(), two boxes at a time.
+__device__ __forceinline__ fx2 slab_pair(fx2 ax, fx2 ay, fx2 az, fx2 bx, fx2 by, fx2 bz, float limit, float far) {
+    const fx2 grow = {1.000001f, 1.000001f};
     fx2 tn, tf;
     tn.x = fmaxf(fmaxf(ax.x, ay.x), fmaxf(az.x, 0.0f));
     tn.y = fmaxf(fmaxf(ax.y, ay.y), fmaxf(az.y, 0.0f));
@@ -490,38 +486,56 @@ __device__ __forceinline__ fx2 slab_pair(fx2 nx, fx2 ny, fx2 nz, fx2 fx, fx2 fy,
     return r;
 }
 
-__device__ __forceinline__ void trav_inner_step(const SceneDev& sc, Trav& t, int* stack) {
-    // Of each axis' two planes the ray crosses the one on the side it comes from first: which of the node's
-    // low / high rows holds a box's near plane depends on the sign of the direction alone, so each lane reads
-    // near and far rows by its own offsets and no per-box minimum / maximum is needed.  Rows: lox at byte 0,
-    // loy 16, loz 32, hix 48, hiy 64, hiz 80 of the node; near ^ mask is the far row.
-    const char* base = reinterpret_cast<const char*>(sc.nodes);
-    const uint32_t at = static_cast<uint32_t>(t.cur) << 7;
-    const uint32_t near_x = at + (t.inv_d.x < 0.0f ? 48u : 0u);
-    const uint32_t near_y = at + (t.inv_d.y < 0.0f ? 64u : 16u);
-    const uint32_t near_z = at + (t.inv_d.z < 0.0f ? 80u : 32u);
-    const float4 nx = *reinterpret_cast<const float4*>(base + near_x), fx = *reinterpret_cast<const float4*>(base + (near_x ^ 48u));
-    const float4 ny = *reinterpret_cast<const float4*>(base + near_y), fy = *reinterpret_cast<const float4*>(base + (near_y ^ 80u));
-    const float4 nz = *reinterpret_cast<const float4*>(base + near_z), fz = *reinterpret_cast<const float4*>(base + (near_z ^ 112u));
-    const int4 ch = *reinterpret_cast<const int4*>(base + (at + 96u));
+__device__ __forceinline__ float ubyte0(uint32_t w) { return static_cast<float>(w & 0xffu); }
+__device__ __forceinline__ float ubyte1(uint32_t w) { return static_cast<float>((w >> 8) & 0xffu); }
+__device__ __forceinline__ float ubyte2(uint32_t w) { return static_cast<float>((w >> 16) & 0xffu); }
+__device__ __forceinline__ float ubyte3(uint32_t w) { return static_cast<float>(w >> 24); }
+
+// Visits four-child node `cur`: the links of the children whose boxes the ray enters within `limit`, nearest first
+// (kBvh4Absent for the rest).  The node is the 64-byte form (Bvh4QNode): a plane lies at org + scale q, so the ray
+// crosses it at q (scale / d) + (org - o) / d -- one multiply-add per plane once the two factors of an axis are made,
+// the offsets q read as bytes.  Of each axis' two planes the ray crosses the one on the side it comes from first,
+// which depends on the sign of the direction alone: the low or the high word is the near one for all four children.
+// The decoded boxes contain the children's (quantize_bvh4), rounding in the three steps stays far below one step of
+// the offsets, which the quantiser gives away on either side, and relative error in the far regime is covered by
+// `grow` as in slab(): the test never drops a box the ray enters.
+__device__ __forceinline__ void trav_visit(const SceneDev& sc, int cur, f3 o, f3 inv_d, float limit, int& c0, int& c1, int& c2, int& c3) {
+    const uint4* q = reinterpret_cast<const uint4*>(sc.nodes) + 4u * static_cast<uint32_t>(cur);
+    const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
+    const int4 ch = *reinterpret_cast<const int4*>(q + 3);
     // Everything below is selects rather than branches: the lanes of a wave take every combination of
     // hit / miss and leaf / node at once, and a branch per case costs more than computing all of them.
     const float far = 3.4e38f;
-    // (origin and reciprocal direction as six values of their own: left grouped in threes, the compiler regroups
-    // them for the packed arithmetic through memory)
-    asm volatile("" : "+v"(t.o.x), "+v"(t.o.y), "+v"(t.o.z), "+v"(t.inv_d.x), "+v"(t.inv_d.y), "+v"(t.inv_d.z));
-    const fx2 t01 = slab_pair(fx2{nx.x, nx.y}, fx2{ny.x, ny.y}, fx2{nz.x, nz.y}, fx2{fx.x, fx.y}, fx2{fy.x, fy.y}, fx2{fz.x, fz.y}, t.o, t.inv_d, t.limit, far);
-    const fx2 t23 = slab_pair(fx2{nx.z, nx.w}, fx2{ny.z, ny.w}, fx2{nz.z, nz.w}, fx2{fx.z, fx.w}, fx2{fy.z, fy.w}, fx2{fz.z, fz.w}, t.o, t.inv_d, t.limit, far);
+    const float Ax = __uint_as_float(q0.w) * inv_d.x, Ay = __uint_as_float(q1.x) * inv_d.y, Az = __uint_as_float(q1.y) * inv_d.z;
+    const float Bx = (__uint_as_float(q0.x) - o.x) * inv_d.x, By = (__uint_as_float(q0.y) - o.y) * inv_d.y, Bz = (__uint_as_float(q0.z) - o.z) * inv_d.z;
+    const bool nx = inv_d.x < 0.0f, ny = inv_d.y < 0.0f, nz = inv_d.z < 0.0f;
+    const uint32_t near_x = nx ? q2.y : q1.z, far_x = nx ? q1.z : q2.y;
+    const uint32_t near_y = ny ? q2.z : q1.w, far_y = ny ? q1.w : q2.z;
+    const uint32_t near_z = nz ? q2.w : q2.x, far_z = nz ? q2.x : q2.w;
+    const fx2 ax2 = splat2(Ax), ay2 = splat2(Ay), az2 = splat2(Az), bx2 = splat2(Bx), by2 = splat2(By), bz2 = splat2(Bz);
+    const fx2 t01 = slab_pair(fma2(fx2{ubyte0(near_x), ubyte1(near_x)}, ax2, bx2), fma2(fx2{ubyte0(near_y), ubyte1(near_y)}, ay2, by2),
+                              fma2(fx2{ubyte0(near_z), ubyte1(near_z)}, az2, bz2), fma2(fx2{ubyte0(far_x), ubyte1(far_x)}, ax2, bx2),
+                              fma2(fx2{ubyte0(far_y), ubyte1(far_y)}, ay2, by2), fma2(fx2{ubyte0(far_z), ubyte1(far_z)}, az2, bz2), limit, far);
+    const fx2 t23 = slab_pair(fma2(fx2{ubyte2(near_x), ubyte3(near_x)}, ax2, bx2), fma2(fx2{ubyte2(near_y), ubyte3(near_y)}, ay2, by2),
+                              fma2(fx2{ubyte2(near_z), ubyte3(near_z)}, az2, bz2), fma2(fx2{ubyte2(far_x), ubyte3(far_x)}, ax2, bx2),
+                              fma2(fx2{ubyte2(far_y), ubyte3(far_y)}, ay2, by2), fma2(fx2{ubyte2(far_z), ubyte3(far_z)}, az2, bz2), limit, far);
     float t0 = t01.x, t1 = t01.y, t2 = t23.x, t3 = t23.y;
     // a child that is not hit is ordered last and marked absent (an entry distance is far below 3.4e38:
     // limits start at 3e38)
-    int c0 = t0 < far ? ch.x : kBvh4Absent, c1 = t1 < far ? ch.y : kBvh4Absent;
-    int c2 = t2 < far ? ch.z : kBvh4Absent, c3 = t3 < far ? ch.w : kBvh4Absent;
+    c0 = t0 < far ? ch.x : kBvh4Absent;
+    c1 = t1 < far ? ch.y : kBvh4Absent;
+    c2 = t2 < far ? ch.z : kBvh4Absent;
+    c3 = t3 < far ? ch.w : kBvh4Absent;
     trav_order(t0, c0, t1, c1);
     trav_order(t2, c2, t3, c3);
     trav_order(t0, c0, t2, c2);
     trav_order(t1, c1, t3, c3);
     trav_order(t1, c1, t2, c2);
+}
+
+__device__ __forceinline__ void trav_inner_step(const SceneDev& sc, Trav& t, int* stack) {
+    int c0, c1, c2, c3;
+    trav_visit(sc, t.cur, t.o, t.inv_d, t.limit, c0, c1, c2, c3);
     // the farther hits wait on the stack, the farthest at the bottom
     if (c3 != kBvh4Absent) {
         stack[t.sp * 256] = c3;
@@ -567,6 +581,7 @@ __device__ __forceinline__ void trav_leaf_step(const SceneDev& sc, Trav& t) {
 // primitives tested (what the traversal's memory traffic is priced by).
 struct TravCounts {
     uint32_t nodes, prims;
+    uint32_t rounds = 0, leaf_steps = 0, restarts = 0;   // wave-uniform (two rays per lane only)
 };
 template <bool COUNT>
 __device__ __forceinline__ void trav_run(const SceneDev& sc, Trav& t, int* stack, uint32_t keep_busy, TravCounts& counts, uint32_t kLeafQuorum = 20u) {
@@ -586,6 +601,146 @@ __device__ __forceinline__ void trav_run(const SceneDev& sc, Trav& t, int* stack
         }
         const uint32_t n_unfinished = static_cast<uint32_t>(__popcll(__ballot(t.busy && !trav_finished(t))));
         if (n_unfinished == 0 || n_unfinished < keep_busy) return;
+    }
+}
+
+// =============================================================================================
+// Two rays per lane.  A lane whose ray waits -- for the wave's next leaf step, or finished and not yet replaced --
+// would idle through the wave's inner steps; with a second ray it visits that ray's nodes meanwhile, so inner steps
+// run with most lanes and leaf steps can wait for a large quorum at no cost.  Both rays' traversal stacks share one
+// LDS column of S entries: ray 0 fills it from the bottom, ray 1 from the top.  Ray 0 is never held up: when its next
+// visit might not find three free entries, ray 1 starts over from the root (it keeps its best hit and limit, so the
+// second pass is cheaper and the result the same -- the closest hit does not depend on the order of the tests); ray 1
+// only advances while three entries are free.  S >= the tree's single-ray need + 3, so a ray alone always finds them.
+// =============================================================================================
+// A ray of a pair, pared down to what must live in registers: `next` is a node link as the tree stores it (>= 0: node to
+// visit, kBvh4Absent: nothing chosen, any other negative value: leaf ~next waiting for the wave's next leaf step);
+// slot ~0: the lane holds no ray here.  The best hit's position goes to the path's slot whenever a hit improves.
+struct PairRay {
+    f3 o, d, inv_d;
+    float limit;
+    unsigned long long best;
+    int next, sp;
+    uint32_t slot;
+};
+constexpr uint32_t kNoSlot = 0xffffffffu;
+__device__ __forceinline__ bool pair_busy(const PairRay& t) { return t.slot != kNoSlot; }
+__device__ __forceinline__ bool pair_wants_leaf(const PairRay& t) { return t.next < 0 && t.next != kBvh4Absent; }
+__device__ __forceinline__ bool pair_can_advance(const PairRay& t) { return t.next >= 0 || (t.next == kBvh4Absent && t.sp > 0); }
+__device__ __forceinline__ bool pair_finished(const PairRay& t) { return pair_busy(t) && t.next == kBvh4Absent && t.sp == 0; }
+__device__ __forceinline__ bool pair_unfinished(const PairRay& t) { return pair_busy(t) && !(t.next == kBvh4Absent && t.sp == 0); }
+__device__ __forceinline__ void pair_idle(PairRay& t) {
+    t.slot = kNoSlot;
+    t.next = kBvh4Absent;
+    t.sp = 0;
+}
+__device__ __forceinline__ void pair_begin(PairRay& t, f3 o, f3 d, uint32_t slot, bool has_nodes) {
+    t.o = o;
+    t.d = d;
+    t.inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    t.limit = 3.0e38f;
+    t.best = kMissKey;
+    t.next = has_nodes ? 0 : kBvh4Absent;
+    t.sp = 0;
+    t.slot = slot;
+}
+
+template <int S, bool COUNT>
+__device__ __forceinline__ void trav_run_pair(const SceneDev& sc, const PathBuffers& pb, PairRay& r0, PairRay& r1, int* col, int rows, uint32_t keep_unfinished,
+                                              TravCounts& counts, uint32_t leaf_quorum) {
+    // rows: entries of the column in use (S, or fewer as a test aid; never below the tree's single-ray need + 3)
+    for (;;) {
+        // ---- one visit per lane: ray 0 if it can go on, else ray 1 ----
+        const bool a0 = pair_can_advance(r0);
+        const bool room = r0.sp + r1.sp + 3 <= rows;
+        if (COUNT) ++counts.rounds;
+        if (a0 && !room && pair_unfinished(r1)) {   // (rare) ray 0 needs the column: ray 1 starts over
+            if (COUNT) ++counts.restarts;
+            r1.next = 0;
+            r1.sp = 0;
+        }
+        const bool a1 = !a0 && room && pair_can_advance(r1);
+        if (a0 || a1) {
+            f3 o = mk3(a1 ? r1.o.x : r0.o.x, a1 ? r1.o.y : r0.o.y, a1 ? r1.o.z : r0.o.z);
+            f3 inv_d = mk3(a1 ? r1.inv_d.x : r0.inv_d.x, a1 ? r1.inv_d.y : r0.inv_d.y, a1 ? r1.inv_d.z : r0.inv_d.z);
+            const float limit = a1 ? r1.limit : r0.limit;
+            int next = a1 ? r1.next : r0.next, sp = a1 ? r1.sp : r0.sp;
+            // entry k of ray 0 at row k, of ray 1 at row rows - 1 - k; `p` is the next free row, `step` the way it grows
+            const int step = a1 ? -256 : 256;
+            int* p = col + (a1 ? (rows - 1 - sp) * 256 : sp * 256);
+            // nothing chosen: take entries off the stack until one is a node, or a leaf whose box the limit still reaches
+            while (next == kBvh4Absent && sp > 0) {
+                --sp;
+                p -= step;
+                const int e = *p;
+                if (e >= 0) {
+                    next = e;
+                } else {
+                    const float4* lb = reinterpret_cast<const float4*>(sc.leaf_boxes) + 2 * static_cast<size_t>(~e);
+                    const float4 lo = lb[0], hi = lb[1];
+                    float tn;
+                    if (slab(o, inv_d, &lo.x, &hi.x, limit, tn)) next = e;
+                }
+            }
+            if (next >= 0) {
+                int c0, c1, c2, c3;
+                trav_visit(sc, next, o, inv_d, limit, c0, c1, c2, c3);
+                if (COUNT) ++counts.nodes;
+                if (c3 != kBvh4Absent) {
+                    *p = c3;
+                    p += step;
+                    ++sp;
+                }
+                if (c2 != kBvh4Absent) {
+                    *p = c2;
+                    p += step;
+                    ++sp;
+                }
+                if (c1 != kBvh4Absent) {
+                    *p = c1;
+                    p += step;
+                    ++sp;
+                }
+                next = c0;   // the nearest is next: a node to visit, a leaf to test, or nothing
+            }
+            r0.next = a1 ? r0.next : next;
+            r0.sp = a1 ? r0.sp : sp;
+            r1.next = a1 ? next : r1.next;
+            r1.sp = a1 ? sp : r1.sp;
+        }
+        // ---- leaf step: when enough lanes hold a pending leaf, or no lane can do anything else ----
+        const bool p0 = pair_wants_leaf(r0), p1 = pair_wants_leaf(r1);
+        const uint32_t n_leaf = static_cast<uint32_t>(__popcll(__ballot(p0 || p1)));
+        if (n_leaf >= leaf_quorum || (n_leaf > 0 && !__ballot(pair_can_advance(r0) || (pair_can_advance(r1) && r0.sp + r1.sp + 3 <= rows)))) {
+            if (COUNT) ++counts.leaf_steps;
+            if (p0 || p1) {
+                const bool l1 = !p0;
+                const f3 o = mk3(l1 ? r1.o.x : r0.o.x, l1 ? r1.o.y : r0.o.y, l1 ? r1.o.z : r0.o.z);
+                const f3 d = mk3(l1 ? r1.d.x : r0.d.x, l1 ? r1.d.y : r0.d.y, l1 ? r1.d.z : r0.d.z);
+                const uint32_t prim = static_cast<uint32_t>(~(l1 ? r1.next : r0.next));
+                const unsigned long long best = l1 ? r1.best : r0.best;
+                if (COUNT) ++counts.prims;
+                PrimRegs pr;
+                load_prim(sc.prims, prim, pr);
+                f3 w;
+                float th;
+                if (hit_analytic(pr, sc.tri_c, prim, o, d, w, th)) {
+                    const unsigned long long key = make_key(th, prim);
+                    if (key < best) {
+                        const float lim = fmaxf(th, 0.0f) * (1.0f / norm_sq(d)) * 1.00001f + 1e-6f;
+                        pb.hit_pos[l1 ? r1.slot : r0.slot] = st4(w);
+                        r0.best = l1 ? r0.best : key;
+                        r0.limit = l1 ? r0.limit : lim;
+                        r1.best = l1 ? key : r1.best;
+                        r1.limit = l1 ? lim : r1.limit;
+                    }
+                }
+                r0.next = l1 ? r0.next : kBvh4Absent;
+                r1.next = l1 ? kBvh4Absent : r1.next;
+            }
+        }
+        const uint32_t n_unfinished = static_cast<uint32_t>(__popcll(__ballot(pair_unfinished(r0))) + __popcll(__ballot(pair_unfinished(r1))));
+        if (n_unfinished == 0 || n_unfinished < keep_unfinished) return;
     }
 }
 
@@ -889,6 +1044,75 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
     if (COUNT) {
         wave_add_total(&pb.totals->node_visits, counts.nodes);
         wave_add_total(&pb.totals->prim_tests, counts.prims);
+    }
+}
+
+// The same with two rays per lane (trav_run_pair): the lane's column of S stack entries is shared by both.
+template <int S, bool COUNT>
+__global__ void __launch_bounds__(256) k_extend_pair(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
+    if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
+    __shared__ int s_stack[S * 256];
+    constexpr uint32_t kCap = S <= 32 ? 256 : 128;   // four blocks share a CU's LDS up to S = 36
+    __shared__ uint32_t s_pend[4 * kCap];
+    PendingQueue to_sdf{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u};
+    const uint32_t n = pb.counters[bounce].n_live;
+    if (static_cast<unsigned long long>(blockIdx.x) * 256u >= n) return;
+    const uint32_t* queue = pb.queue[bounce & 1];
+    uint32_t* heads = pb.counters[bounce].extend_head;
+    int* col = s_stack + threadIdx.x;
+    const int rows = bp.pair_rows ? min(static_cast<int>(bp.pair_rows), S) : S;
+    f3 box_lo = mk3(0, 0, 0), box_hi = mk3(0, 0, 0);
+    if (sc.n_sdf) {
+        box_lo = mk3(sc.sdf_boxes[0].lo[0], sc.sdf_boxes[0].lo[1], sc.sdf_boxes[0].lo[2]);
+        box_hi = mk3(sc.sdf_boxes[0].hi[0], sc.sdf_boxes[0].hi[1], sc.sdf_boxes[0].hi[2]);
+    }
+    uint32_t n_sdf_rays = 0;
+    XcdCursor cursor{0u, 0u, blockIdx.x & 7u, 0u};
+    PairRay r0, r1;
+    r0.o = r0.d = r0.inv_d = r1.o = r1.d = r1.inv_d = mk3(0, 0, 0);
+    r0.limit = r1.limit = 0.0f;
+    r0.best = r1.best = kMissKey;
+    pair_idle(r0);
+    pair_idle(r1);
+    TravCounts counts{0u, 0u};
+    // a finished ray leaves its result and makes room; an idle slot takes the next ray of the queue
+    auto turn_over = [&](PairRay& t) {
+        bool wants_sdf = false;
+        const uint32_t slot_was = t.slot;
+        if (pair_finished(t)) {
+            pb.hit_key[t.slot] = t.best;
+            if (t.best == kMissKey) pb.hit_pos[t.slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, t.o, t.d, t.inv_d, t.limit, !(bp.flags & kFlagFullMarch));
+            pair_idle(t);
+        }
+        pending_push(to_sdf, wants_sdf, slot_was, &pb.counters[bounce].n_sdf, pb.sdf_queue);
+        n_sdf_rays += wants_sdf ? 1u : 0u;
+        uint32_t i = 0;
+        if (xcd_cursor_take(cursor, !pair_busy(t) && !xcd_cursor_empty(cursor), heads, n, i)) {
+            const uint32_t slot = queue[i];
+            pair_begin(t, ld3(pb.ray_o[slot]), ld3(pb.ray_d[slot]), slot, sc.nodes != nullptr);
+        }
+    };
+    for (;;) {
+        turn_over(r0);
+        turn_over(r1);
+        if (!__ballot(pair_busy(r0) || pair_busy(r1))) {
+            if (xcd_cursor_empty(cursor)) break;
+            continue;
+        }
+        const uint32_t n_busy = static_cast<uint32_t>(__popcll(__ballot(pair_busy(r0))) + __popcll(__ballot(pair_busy(r1))));
+        trav_run_pair<S, COUNT>(sc, pb, r0, r1, col, rows, xcd_cursor_empty(cursor) ? 0u : (bp.trav_keep_pair * n_busy) / 128u, counts, bp.trav_quorum_pair);
+    }
+    pending_flush(to_sdf, &pb.counters[bounce].n_sdf, pb.sdf_queue);
+    wave_add_total(&pb.totals->sdf_rays, n_sdf_rays);
+    if (COUNT) {
+        wave_add_total(&pb.totals->node_visits, counts.nodes);
+        wave_add_total(&pb.totals->prim_tests, counts.prims);
+        wave_add_total(&pb.totals->trav_restarts, counts.restarts);   // per lane
+        if (__lane_id() == 0) {
+            atomicAdd(&pb.totals->trav_rounds, static_cast<unsigned long long>(counts.rounds));
+            atomicAdd(&pb.totals->trav_leaf_steps, static_cast<unsigned long long>(counts.leaf_steps));
+        }
     }
 }
 
@@ -1738,6 +1962,21 @@ void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, co
         if (count) hipLaunchKernelGGL((k_extend<STACK, true>), grid, block, 0, st, sc, bp, pb, bounce); \
         else hipLaunchKernelGGL((k_extend<STACK, false>), grid, block, 0, st, sc, bp, pb, bounce);      \
     } while (0)
+#define MIPT_LAUNCH_EXP(STACK)                                                                               \
+    do {                                                                                                   \
+        if (count) hipLaunchKernelGGL((k_extend_pair<STACK, true>), grid, block, 0, st, sc, bp, pb, bounce); \
+        else hipLaunchKernelGGL((k_extend_pair<STACK, false>), grid, block, 0, st, sc, bp, pb, bounce);      \
+    } while (0)
+    if (bp.trav_quorum_pair) {
+        // two rays per lane: one column of S entries for both (S >= the tree's need + 3: the second ray asks for three free rows before every visit, and must find them when it is alone)
+        if (stack_need + 3 <= 16) MIPT_LAUNCH_EXP(16);
+        else if (stack_need + 3 <= 32) MIPT_LAUNCH_EXP(32);
+        else if (stack_need + 3 <= 36) MIPT_LAUNCH_EXP(36);
+        else if (stack_need + 3 <= 40) MIPT_LAUNCH_EXP(40);
+        else MIPT_LAUNCH_EXP(63);
+        return;
+    }
+#undef MIPT_LAUNCH_EXP
     if (stack_need <= 8) MIPT_LAUNCH_EX(8);
     else if (stack_need <= 24) MIPT_LAUNCH_EX(24);
     else if (stack_need <= 32) MIPT_LAUNCH_EX(32);

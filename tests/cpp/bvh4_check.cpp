@@ -107,6 +107,28 @@ int main(int argc, char** argv) {
         if (w.seen[p]) return fail("a primitive that was never given is a leaf", p);
     if (w.max_stack > four.stack_need) return fail("walk needs more stack than reported", w.max_stack, four.stack_need);
     if (four.stack_need > 3 * four.depth) return fail("stack need beyond three per level", four.stack_need, four.depth);
+    // the 64-byte form the kernels read: same links, every decoded box contains the child's and stays within two steps of it
+    const std::vector<Bvh4QNode> q = quantize_bvh4(four.nodes);
+    if (q.size() != four.nodes.size()) return fail("quantised node count");
+    for (size_t i = 0; i < q.size(); ++i) {
+        const Bvh4Node& nd = four.nodes[i];
+        const float* lo[3] = {nd.lox, nd.loy, nd.loz};
+        const float* hi[3] = {nd.hix, nd.hiy, nd.hiz};
+        for (int k = 0; k < 4; ++k) {
+            if (q[i].child[k] != nd.child[k]) return fail("quantised link differs", static_cast<long>(i), k);
+            for (int a = 0; a < 3; ++a) {
+                const uint32_t ql = (q[i].qlo[a] >> (8 * k)) & 0xffu, qh = (q[i].qhi[a] >> (8 * k)) & 0xffu;
+                if (nd.child[k] == kBvh4Absent) {
+                    if (ql != 255u || qh != 0u) return fail("absent child's offsets", static_cast<long>(i), k);
+                    continue;
+                }
+                if (!(q[i].scale[a] > 0.0f)) return fail("step not positive", static_cast<long>(i), a);
+                const float dl = bvh4q_plane(q[i], a, ql), dh = bvh4q_plane(q[i], a, qh);
+                if (!(dl <= lo[a][k] && dh >= hi[a][k])) return fail("decoded box does not contain the child's", static_cast<long>(i), k);
+                if (lo[a][k] - dl > 2.001f * q[i].scale[a] || dh - hi[a][k] > 2.001f * q[i].scale[a]) return fail("decoded box looser than two steps", static_cast<long>(i), k);
+            }
+        }
+    }
     size_t kids = 0;
     for (const Bvh4Node& nd : four.nodes)
         for (int k = 0; k < 4; ++k) kids += nd.child[k] != kBvh4Absent;
