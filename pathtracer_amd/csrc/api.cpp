@@ -56,6 +56,7 @@ struct mipt_ctx {
     bool full_march = false;        // MIPT_FULL_MARCH=1: no shortcut for SDF marches that cannot end (for the equivalence test)
     uint32_t lane_threshold = 14;   // MIPT_LANE_THRESHOLD: 1 = always one point per lane, 65 = never
     int min_stack = 0;   // MIPT_MIN_STACK: the traversal kernels are picked as if every tree needed at least this many stack entries (a test aid)
+    bool pair_plain = false;   // MIPT_PAIR_PLAIN=1 (test aid): stack entries carry no entry distance, as in trees too large for the packed form
     bool pair_tight = false;   // MIPT_PAIR_TIGHT=1 (test aid): the two rays of a lane share only as many stack rows as one ray can need (+ 3), so the second ray starts over often
     uint32_t trav_quorum_pair = 32, trav_keep_pair = 76;   // MIPT_PAIR_QUORUM (0: one ray per lane), MIPT_PAIR_KEEP: the same with two rays per lane
     uint32_t trav_quorum = 20, trav_quorum_primary = 2, trav_keep = 40;   // MIPT_LEAF_QUORUM, MIPT_LEAF_QUORUM_PRIMARY, MIPT_KEEP_BUSY: scheduling of the BVH traversal's two phases (tuning aids)
@@ -623,6 +624,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
     bp.trav_keep = c->trav_keep;
     bp.trav_quorum_pair = c->trav_quorum_pair;
     bp.trav_keep_pair = c->trav_keep_pair;
+    bp.pair_plain_entries = c->pair_plain ? 1u : 0u;
     bp.pair_rows = c->pair_tight ? static_cast<uint32_t>(std::max(sc->stack_need, c->min_stack)) + 3u : 0u;
         bp.seed = st->seed;
         HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
@@ -735,6 +737,7 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
     if (const char* e = std::getenv("MIPT_LEAF_QUORUM_PRIMARY")) c->trav_quorum_primary = static_cast<uint32_t>(std::min(64L, std::max(1L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_MIN_STACK")) c->min_stack = static_cast<int>(std::min(long(kMaxTraversalStack), std::max(0L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_PAIR_QUORUM")) c->trav_quorum_pair = static_cast<uint32_t>(std::min(64L, std::max(0L, std::atol(e))));
+    if (const char* e = std::getenv("MIPT_PAIR_PLAIN")) c->pair_plain = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_PAIR_TIGHT")) c->pair_tight = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_PAIR_KEEP")) c->trav_keep_pair = static_cast<uint32_t>(std::min(128L, std::max(0L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_KEEP_BUSY")) c->trav_keep = static_cast<uint32_t>(std::min(64L, std::max(0L, std::atol(e))));
@@ -1099,6 +1102,7 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
     s->dev.crater_masks = static_cast<const unsigned long long*>(s->d_crater_masks);
     s->dev.n_sdf = static_cast<uint32_t>(sdf.size());
     s->dev.n_prims = n;
+    s->dev.n_nodes = static_cast<uint32_t>(qnodes.size());
     s->dev.host_boxes = static_cast<const SdfBox*>(s->d_host_boxes);
     s->dev.n_host = static_cast<uint32_t>(host_boxes.size());
     for (const SdfBox& hb : host_boxes) s->host_prims.push_back(hb.prim);
@@ -1326,6 +1330,7 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     bp.trav_keep = c->trav_keep;
     bp.trav_quorum_pair = c->trav_quorum_pair;
     bp.trav_keep_pair = c->trav_keep_pair;
+    bp.pair_plain_entries = c->pair_plain ? 1u : 0u;
     bp.pair_rows = c->pair_tight ? static_cast<uint32_t>(std::max(sc->stack_need, c->min_stack)) + 3u : 0u;
     mipt_camera c0 = *cam;
     c0.blur_radius = 0.0f;
@@ -1383,6 +1388,7 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     bp.trav_keep = c->trav_keep;
     bp.trav_quorum_pair = c->trav_quorum_pair;
     bp.trav_keep_pair = c->trav_keep_pair;
+    bp.pair_plain_entries = c->pair_plain ? 1u : 0u;
     bp.pair_rows = c->pair_tight ? static_cast<uint32_t>(std::max(sc->stack_need, c->min_stack)) + 3u : 0u;
     bp.flags = c->full_march ? kFlagFullMarch : 0u;
     bp.seed = seed;

@@ -88,6 +88,7 @@ struct SceneDev {
     const SdfBox* sdf_boxes;
     uint32_t n_sdf;
     uint32_t n_prims;
+    uint32_t n_nodes;              // four-child nodes of the tree
     // noise() (PathTracerDemo.cpp:56-70) unrolled: octave i samples A_i p + b_i with weight k_i; 13 floats per octave (A row-major,
     // b + 0.25, k), 8 octaves (null when the scene has no crater ball)
     const float* noise_oct;

@@ -54,6 +54,7 @@ struct BatchParams {
     uint32_t trav_keep;        // BVH traversal: a wave refills its idle lanes when fewer than trav_keep / 64 of its busy lanes are unfinished (40)
     uint32_t trav_quorum_pair;   // two rays per lane (0: one ray per lane): lanes with a pending leaf from which a wave runs a leaf step
     uint32_t trav_keep_pair;     // ... and a wave turns its finished rays over when fewer than trav_keep_pair / 128 of its rays are unfinished
+    uint32_t pair_plain_entries; // test aid: stack entries without entry distances, as trees beyond 2^20 nodes or primitives get them
     uint32_t pair_rows;          // test aid: rows of the shared stack column in use (0: all; at least the tree's need + 3)
     uint64_t seed;
 };

@@ -499,7 +499,8 @@ __device__ __forceinline__ float ubyte3(uint32_t w) { return static_cast<float>(
 // The decoded boxes contain the children's (quantize_bvh4), rounding in the three steps stays far below one step of
 // the offsets, which the quantiser gives away on either side, and relative error in the far regime is covered by
 // `grow` as in slab(): the test never drops a box the ray enters.
-__device__ __forceinline__ void trav_visit(const SceneDev& sc, int cur, f3 o, f3 inv_d, float limit, int& c0, int& c1, int& c2, int& c3) {
+__device__ __forceinline__ void trav_visit(const SceneDev& sc, int cur, f3 o, f3 inv_d, float limit, int& c0, int& c1, int& c2, int& c3, float& e1, float& e2,
+                                           float& e3) {
     const uint4* q = reinterpret_cast<const uint4*>(sc.nodes) + 4u * static_cast<uint32_t>(cur);
     const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
     const int4 ch = *reinterpret_cast<const int4*>(q + 3);
@@ -531,11 +532,15 @@ __device__ __forceinline__ void trav_visit(const SceneDev& sc, int cur, f3 o, f3
     trav_order(t0, c0, t2, c2);
     trav_order(t1, c1, t3, c3);
     trav_order(t1, c1, t2, c2);
+    e1 = t1;   // where the ray enters the deferred children
+    e2 = t2;
+    e3 = t3;
 }
 
 __device__ __forceinline__ void trav_inner_step(const SceneDev& sc, Trav& t, int* stack) {
     int c0, c1, c2, c3;
-    trav_visit(sc, t.cur, t.o, t.inv_d, t.limit, c0, c1, c2, c3);
+    float e1, e2, e3;
+    trav_visit(sc, t.cur, t.o, t.inv_d, t.limit, c0, c1, c2, c3, e1, e2, e3);
     // the farther hits wait on the stack, the farthest at the bottom
     if (c3 != kBvh4Absent) {
         stack[t.sp * 256] = c3;
@@ -645,7 +650,19 @@ __device__ __forceinline__ void pair_begin(PairRay& t, f3 o, f3 d, uint32_t slot
     t.slot = slot;
 }
 
-template <int S, bool COUNT>
+// A deferred child on the stack with the distance at which the ray enters its box: link in the upper 21 bits (node
+// index, or 2^20 + primitive for a leaf), the top 11 bits of the distance's float pattern -- sign (never set), exponent,
+// three bits of mantissa, i.e. rounded down by at most an eighth -- in the lower 11.  An entry whose distance lies
+// beyond the limit the ray has reached by the time it comes off the stack is dropped there and then: no node fetch, no
+// leaf-box fetch.  For trees of up to 2^20 nodes and 2^20 primitives (DIST); larger ones keep plain links and the leaf
+// boxes' re-test.
+constexpr uint32_t kEntryLeaf = 1u << 20;
+__device__ __forceinline__ int entry_pack(int c, float t) {
+    const uint32_t link = c >= 0 ? static_cast<uint32_t>(c) : (kEntryLeaf | static_cast<uint32_t>(~c));
+    return static_cast<int>((link << 11) | (__float_as_uint(t) >> 20));
+}
+
+template <int S, bool COUNT, bool DIST>
 __device__ __forceinline__ void trav_run_pair(const SceneDev& sc, const PathBuffers& pb, PairRay& r0, PairRay& r1, int* col, int rows, uint32_t keep_unfinished,
                                               TravCounts& counts, uint32_t leaf_quorum) {
     // rows: entries of the column in use (S, or fewer as a test aid; never below the tree's single-ray need + 3)
@@ -673,7 +690,12 @@ __device__ __forceinline__ void trav_run_pair(const SceneDev& sc, const PathBuff
                 --sp;
                 p -= step;
                 const int e = *p;
-                if (e >= 0) {
+                if (DIST) {
+                    const uint32_t u = static_cast<uint32_t>(e);
+                    if (((u & 0x7ffu) << 20) > __float_as_uint(limit)) continue;   // entered beyond the limit (both patterns are of non-negative floats)
+                    const uint32_t link = u >> 11;
+                    next = (link & kEntryLeaf) ? ~static_cast<int>(link & (kEntryLeaf - 1u)) : static_cast<int>(link);
+                } else if (e >= 0) {
                     next = e;
                 } else {
                     const float4* lb = reinterpret_cast<const float4*>(sc.leaf_boxes) + 2 * static_cast<size_t>(~e);
@@ -684,20 +706,21 @@ __device__ __forceinline__ void trav_run_pair(const SceneDev& sc, const PathBuff
             }
             if (next >= 0) {
                 int c0, c1, c2, c3;
-                trav_visit(sc, next, o, inv_d, limit, c0, c1, c2, c3);
+                float e1, e2, e3;
+                trav_visit(sc, next, o, inv_d, limit, c0, c1, c2, c3, e1, e2, e3);
                 if (COUNT) ++counts.nodes;
                 if (c3 != kBvh4Absent) {
-                    *p = c3;
+                    *p = DIST ? entry_pack(c3, e3) : c3;
                     p += step;
                     ++sp;
                 }
                 if (c2 != kBvh4Absent) {
-                    *p = c2;
+                    *p = DIST ? entry_pack(c2, e2) : c2;
                     p += step;
                     ++sp;
                 }
                 if (c1 != kBvh4Absent) {
-                    *p = c1;
+                    *p = DIST ? entry_pack(c1, e1) : c1;
                     p += step;
                     ++sp;
                 }
@@ -1048,7 +1071,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
 }
 
 // The same with two rays per lane (trav_run_pair): the lane's column of S stack entries is shared by both.
-template <int S, bool COUNT>
+template <int S, bool COUNT, bool DIST>
 __global__ void __launch_bounds__(256) k_extend_pair(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
     if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
     __shared__ int s_stack[S * 256];
@@ -1101,7 +1124,7 @@ __global__ void __launch_bounds__(256) k_extend_pair(SceneDev sc, BatchParams bp
             continue;
         }
         const uint32_t n_busy = static_cast<uint32_t>(__popcll(__ballot(pair_busy(r0))) + __popcll(__ballot(pair_busy(r1))));
-        trav_run_pair<S, COUNT>(sc, pb, r0, r1, col, rows, xcd_cursor_empty(cursor) ? 0u : (bp.trav_keep_pair * n_busy) / 128u, counts, bp.trav_quorum_pair);
+        trav_run_pair<S, COUNT, DIST>(sc, pb, r0, r1, col, rows, xcd_cursor_empty(cursor) ? 0u : (bp.trav_keep_pair * n_busy) / 128u, counts, bp.trav_quorum_pair);
     }
     pending_flush(to_sdf, &pb.counters[bounce].n_sdf, pb.sdf_queue);
     wave_add_total(&pb.totals->sdf_rays, n_sdf_rays);
@@ -1964,10 +1987,14 @@ void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, co
     } while (0)
 #define MIPT_LAUNCH_EXP(STACK)                                                                               \
     do {                                                                                                   \
-        if (count) hipLaunchKernelGGL((k_extend_pair<STACK, true>), grid, block, 0, st, sc, bp, pb, bounce); \
-        else hipLaunchKernelGGL((k_extend_pair<STACK, false>), grid, block, 0, st, sc, bp, pb, bounce);      \
+        if (count) hipLaunchKernelGGL((k_extend_pair<STACK, true, true>), grid, block, 0, st, sc, bp, pb, bounce);          \
+        else if (dist) hipLaunchKernelGGL((k_extend_pair<STACK, false, true>), grid, block, 0, st, sc, bp, pb, bounce);    \
+        else hipLaunchKernelGGL((k_extend_pair<STACK, false, false>), grid, block, 0, st, sc, bp, pb, bounce);             \
     } while (0)
-    if (bp.trav_quorum_pair) {
+    // stack entries that carry their entry distance: the tree's links must fit 20 bits (the counting build is only
+    // instantiated for such trees; larger ones are counted by the one-ray kernels)
+    const bool dist = sc.n_prims <= (1u << 20) && sc.n_nodes <= (1u << 20) && !bp.pair_plain_entries;
+    if (bp.trav_quorum_pair && stack_need > 8 && (dist || !count)) {
         // two rays per lane: one column of S entries for both (S >= the tree's need + 3: the second ray asks for three free rows before every visit, and must find them when it is alone)
         if (stack_need + 3 <= 16) MIPT_LAUNCH_EXP(16);
         else if (stack_need + 3 <= 32) MIPT_LAUNCH_EXP(32);

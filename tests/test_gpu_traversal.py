@@ -52,29 +52,32 @@ def test_culled_traversal_equals_the_scan_over_every_object(n, extent, radius_sc
     assert st_scan["rays"] > 1.5 * st_scan["paths"] * 0.05
     for name, env in (("two rays per lane", {"MIPT_NO_CULL": "0"}), ("one ray per lane", {"MIPT_NO_CULL": "0", "MIPT_PAIR_QUORUM": "0"}),
                       ("two rays per lane, leaf steps at once", {"MIPT_NO_CULL": "0", "MIPT_PAIR_QUORUM": "1", "MIPT_PAIR_KEEP": "128"}),
-                      ("two rays per lane, late leaf steps", {"MIPT_NO_CULL": "0", "MIPT_PAIR_QUORUM": "64", "MIPT_PAIR_KEEP": "16"})):
+                      ("two rays per lane, late leaf steps", {"MIPT_NO_CULL": "0", "MIPT_PAIR_QUORUM": "64", "MIPT_PAIR_KEEP": "16"}),
+                      ("two rays per lane, stack entries without distances", {"MIPT_NO_CULL": "0", "MIPT_PAIR_PLAIN": "1"})):
         img, st = _render(flat, cam, w, spp, bounces, env)
         assert st["rays"] == st_scan["rays"], (name, st["rays"], st_scan["rays"])
         assert np.array_equal(img, scan), name
 
 
 def test_shared_stack_column_overflow_restarts_the_second_ray():
-    """A tree much deeper than the column two rays share (objects strung along a line, boxes nesting and overlapping;
-    MIPT_PAIR_TIGHT=1 leaves the pair only as many rows as one ray of this tree can need): ray 1 of a lane starts over
-    whenever ray 0 needs the room, and the frame is still the one-ray-per-lane frame and the scan's."""
+    """Concentric spheres: every box holds the next, so a ray that aims at the middle enters all of them, and both rays of
+    a lane push a deep stack on their way down before any leaf has been tested.  MIPT_PAIR_TIGHT=1 leaves the pair only
+    the rows one ray of this tree can need (+ 3): ray 1 of a lane starts over whenever ray 0 needs the room, and the
+    frame is still the one-ray-per-lane frame and the scan's."""
     alg = api.HostAlgebra()
-    n = 1500
-    flat = S.random_scene(alg, n, seed=5, radius_scale=4.0, extent=0.5)
-    # string the objects along a line so that boxes nest and overlap heavily: deep stacks in every walk
-    t = np.linspace(-4.0, 4.0, n).astype(np.float32)
-    flat.fwd[:, 9], flat.fwd[:, 10], flat.fwd[:, 11] = t, 0.6 * t, 0.25 * t
+    n = 400
+    flat = S.random_scene(alg, n, seed=5)
+    flat.kind[:] = S.SPHERE
+    flat.fwd[:] = 0.0
+    flat.fwd[:, 0] = flat.fwd[:, 4] = flat.fwd[:, 8] = 1.0
+    flat.params[:] = 0.0
+    flat.params[:, 0] = (0.5 * 1.006 ** np.arange(n)).astype(np.float32)
     flat.inv[:] = alg.affine_inverse_batch(flat.fwd)
     cam = S.random_scene_camera(alg, 1.0)
     w, spp, bounces = 256, 8, 6
     one, st_one = _render(flat, cam, w, spp, bounces, {"MIPT_PAIR_QUORUM": "0"})
     two, st_two = _render(flat, cam, w, spp, bounces, {"MIPT_PAIR_QUORUM": "32", "MIPT_PAIR_TIGHT": "1"}, counting=True)
-    print("second rays started over:", st_two["trav_restarts"], "of", st_two["rays"], "rays; lanes at work per round:",
-          round(st_two["node_visits"] / max(1, st_two["trav_rounds"]), 1))
+    print("second rays started over:", st_two["trav_restarts"], "times in", st_two["rays"], "rays")
     assert st_two["trav_restarts"] > 0, "the scene was meant to overflow the shared column"
     assert st_one["rays"] == st_two["rays"] and np.array_equal(one, two)
     scan, st_scan = _render(flat, cam, w, spp, bounces, {"MIPT_NO_CULL": "1"})
