@@ -49,8 +49,12 @@ PEAK_HBM_GBS = 8000.0
 # every workgroup: 16.8-18.8 TB/s): the ceiling of a traversal whose nodes stay in L2.
 L2_GATHER_GBS = 17800.0
 # Algorithmic bytes of the closest-hit kernels: per ray 32 B read (origin, direction) + 24 B written (hit key, hit
-# position); per node visit one 64-byte BVH2 node (both children's boxes + links); per primitive test one 128-byte record.
-BYTES_PER_RAY, BYTES_PER_NODE, BYTES_PER_PRIM_TEST = 56, 128, 128
+# position); per node visit one 64-byte four-child node (quantised boxes + links); per primitive test one 128-byte record.
+BYTES_PER_RAY, BYTES_PER_NODE, BYTES_PER_PRIM_TEST = 56, 64, 128
+# What bounds the traversal is the vector-memory pipeline in front of the caches: every load instruction costs address
+# and tag processing per lane, and a lane fetches its node / record in 16-byte pieces.  Its ceiling in bytes: 64 B per
+# clock and CU through the vector L1.
+L1_GBS = 64.0 * 256 * 2.4
 
 
 def parse():
@@ -322,22 +326,26 @@ def main():
                 ("random1m", 3840, 2160, 32): "random1m_4k_32spp"}.get((a.scene, W, H, a.spp))
         if prof and world == 1:
             path = os.path.join(ROOT, "profiles", f"r02_pmc_fetch_{prof}.csv")
-            ext, gen = pmc_rows(path, "k_extend<"), pmc_rows(path, "k_generate_extend<")   # the first rows are the plain (not the counting) builds
+            ext, gen = pmc_rows(path, "k_extend"), pmc_rows(path, "k_generate_extend<")   # the first rows are the plain (not the counting) builds
             if ext and gen:
                 traffic = 2.0 * (ext["FETCH_SIZE"] + gen["FETCH_SIZE"]) * 1024.0 / max(1.0, ext["dispatches"] + gen["dispatches"])
                 traffic_source = f"profiles/r02_pmc_fetch_{prof}.csv: 2 x FETCH_SIZE KB per launch (reads that go past L2; wide reads corrected x2)"
         out["roofline"] = {"kernel": "k_generate_extend + k_extend (closest hit)", "bound": "hbm",
-                           "bound_detail": "gather of 128-B four-child nodes and 128-B primitive records, served mostly from L2 / Infinity Cache; measured limiter: vector issue at partial lane occupancy",
+                           "bound_detail": "gather of 64-B four-child nodes and 128-B primitive records, served mostly from L1 / L2 / Infinity Cache; measured limiter: "
+                                           "the vector-memory pipeline (load instructions x lanes: time follows the number of 16-byte pieces fetched, not the arithmetic)",
                            "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                            "frac": achieved / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_source,
                            "avg_launch_ms": trav_ms / n_launch, "launches": n_launch,
                            "l2_gather_peak": L2_GATHER_GBS, "frac_of_l2_gather": achieved / L2_GATHER_GBS,
+                           "l1_peak": L1_GBS, "frac_of_l1": achieved / L1_GBS,
+                           "pieces_per_ray": (4 * cst["node_visits"] + 8 * cst["prim_tests"]) / max(1, cst["rays"]) + 3.0,
                            "node_visits_per_ray": cst["node_visits"] / max(1, cst["rays"]), "prim_tests_per_ray": cst["prim_tests"] / max(1, cst["rays"]),
                            "bytes_per_ray": bytes_alg / max(1, cst["rays"]),
-                           "note": "bytes = rays*56 + node_visits*128 + prim_tests*128 per frame (counting build, one extra frame outside the timed region) over "
-                                   "the frame's closest-hit kernel time (HIP events); the tree (6.5 MB of nodes + 12.8 MB of records at 100k objects) "
+                           "note": "bytes = rays*56 + node_visits*64 + prim_tests*128 per frame (counting build, one extra frame outside the timed region) over "
+                                   "the frame's closest-hit kernel time (HIP events); the tree (3.2 MB of nodes + 12.8 MB of records at 100k objects) "
                                    "fits the caches, so algorithmic bytes per second exceed what HBM moves (frac > 1 against the HBM peak); "
-                                   "frac_of_l2_gather prices the same bytes against the chip's L2 gather rate"}
+                                   "frac_of_l2_gather and frac_of_l1 price the same bytes against the chip's L2 gather rate and the vector L1s' 64 B per "
+                                   "clock and CU; pieces_per_ray = the 16-byte loads a ray's lane issues (4 per node visit, 8 per primitive test, 3 per ray)"}
 
     # ---- CPU baseline: the restated reference renderer on a bounded sample ----------------------
     if not a.no_cpu_baseline and world == 1:

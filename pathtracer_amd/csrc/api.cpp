@@ -860,6 +860,7 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
         std::memcpy(r.fwd, d->fwd + 12 * static_cast<size_t>(i), sizeof(r.fwd));
         const float* p = d->params + 9 * static_cast<size_t>(i);
         std::memcpy(r.p, p, sizeof(r.p));
+        std::memcpy(r.q, p + 3, sizeof(r.q));
         r.kind = d->kind[i];
         r.material = d->material[i];
         if (r.kind == MIPT_TRIANGLE) std::memcpy(&tri_c[3 * static_cast<size_t>(i)], p + 6, sizeof(float) * 3);
@@ -875,7 +876,7 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
             // (src/Object.cpp:161): keep that box as AxisAlignedBox(Pos, Pos) forms it (src/Geometry.cpp:348-358)
             for (int a = 0; a < 3; ++a) {
                 r.p[a] = lo[a] + 0.5f * (hi[a] - lo[a]);
-                r.p[3 + a] = 0.5f * std::fabs(lo[a] - hi[a]);
+                r.q[a] = 0.5f * std::fabs(lo[a] - hi[a]);
             }
         }
         // The reference's hits lie inside its padded boxes (1e-3 in local units); widen a little more
@@ -1014,8 +1015,8 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
                         }
             }
             const uint32_t packed = count | (ordinal << 8);
-            std::memcpy(&r.p[3], &first, 4);
-            std::memcpy(&r.p[4], &packed, 4);
+            std::memcpy(&r.q[0], &first, 4);
+            std::memcpy(&r.q[1], &packed, 4);
         }
         (void)hipFree(d_cells);
     }

@@ -4,14 +4,25 @@
 
 namespace mipt {
 
-// One primitive = one 128-byte line: a lane that tests or shades a primitive fetches exactly one
-// cache line (8 x dwordx4).  Affines are Linear row-major (m[3*r+c]) followed by the translation.
+// One primitive = one 128-byte line in two halves.  The first 64 bytes are all that Object::hitRay's test of a sphere or
+// a box reads (four 16-byte pieces per lane: the traversal is bound by the pieces it fetches); the second half is
+// read when the test hits (the way back to world space) and by the stages after it.  Affines are Linear row-major
+// (m[3*r+c]) followed by the translation.
 struct alignas(128) PrimRec {
     float inv[12];      // world -> local  (Object::m_inverseTransformation)
-    float fwd[12];      // local -> world  (Object::m_transformation)
-    float p[6];         // sphere {r}; box {hx,hy,hz}; crater ball {offset, first crater, craters}; rough box {halfSize}; fractal {world box}; triangle {a, b} (c in tri_c)
+    float p[3];         // parameters 0-2: sphere {r}; box {hx,hy,hz}; crater ball {offset}; rough box {halfSize}; fractal {world box centre}; triangle {a}
     uint32_t kind;
+    float fwd[12];      // local -> world  (Object::m_transformation)
+    float q[3];         // parameters 3-5: crater ball {first crater, craters}; fractal {world box half size}; triangle {b} (c in tri_c)
     uint32_t material;
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    float& param(int i) { return i < 3 ? p[i] : q[i - 3]; }
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    const float& param(int i) const { return i < 3 ? p[i] : q[i - 3]; }
 };
 static_assert(sizeof(PrimRec) == 128, "PrimRec must be one 128-byte line");
 
@@ -93,11 +104,11 @@ struct SceneDev {
     // b + 0.25, k), 8 octaves (null when the scene has no crater ball)
     const float* noise_oct;
     // big craters of every crater ball: 12 floats per crater {cell.xyz, size, on_sphere.xyz, t, age bits, 1/(5 size), -, -};
-    // a ball's records start at record PrimRec::p[3] and number PrimRec::p[4] (both uint32 bit patterns)
+    // a ball's records start at record PrimRec::q[0] and number PrimRec::q[1] (both uint32 bit patterns)
     const float* craters;
     // per crater ball, in the order of their tables: for each of the 9^3 lattice cells about floor(offset) - 4 that a
     // query can fall into, the mask of table entries within the 4^3 cells the reference visits from there; the ball's
-    // ordinal sits above the low 8 bits of PrimRec::p[4]
+    // ordinal sits above the low 8 bits of PrimRec::q[1]
     const unsigned long long* crater_masks;
     // the raw noise transform (Linear row-major, then the translation), read by the SDF kinds that run noise() octave by octave
     const float* noise_raw;

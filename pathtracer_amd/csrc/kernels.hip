@@ -256,21 +256,29 @@ struct PrimRegs {
     float inv[12], fwd[12], p[6];
     uint32_t kind, material;
 };
-__device__ __forceinline__ void load_prim(const PrimRec* prims, uint32_t i, PrimRegs& r) {
+// First half of a record: what the test of a sphere or a box reads.
+__device__ __forceinline__ void load_prim_test(const PrimRec* prims, uint32_t i, PrimRegs& r) {
     const float4* src = reinterpret_cast<const float4*>(prims + i);
-    float4 v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = src[k];
-    r.inv[0] = v[0].x; r.inv[1] = v[0].y; r.inv[2] = v[0].z; r.inv[3] = v[0].w;
-    r.inv[4] = v[1].x; r.inv[5] = v[1].y; r.inv[6] = v[1].z; r.inv[7] = v[1].w;
-    r.inv[8] = v[2].x; r.inv[9] = v[2].y; r.inv[10] = v[2].z; r.inv[11] = v[2].w;
-    r.fwd[0] = v[3].x; r.fwd[1] = v[3].y; r.fwd[2] = v[3].z; r.fwd[3] = v[3].w;
-    r.fwd[4] = v[4].x; r.fwd[5] = v[4].y; r.fwd[6] = v[4].z; r.fwd[7] = v[4].w;
-    r.fwd[8] = v[5].x; r.fwd[9] = v[5].y; r.fwd[10] = v[5].z; r.fwd[11] = v[5].w;
-    r.p[0] = v[6].x; r.p[1] = v[6].y; r.p[2] = v[6].z; r.p[3] = v[6].w;
-    r.p[4] = v[7].x; r.p[5] = v[7].y;
-    r.kind = __float_as_uint(v[7].z);
-    r.material = __float_as_uint(v[7].w);
+    const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+    r.inv[0] = v0.x; r.inv[1] = v0.y; r.inv[2] = v0.z; r.inv[3] = v0.w;
+    r.inv[4] = v1.x; r.inv[5] = v1.y; r.inv[6] = v1.z; r.inv[7] = v1.w;
+    r.inv[8] = v2.x; r.inv[9] = v2.y; r.inv[10] = v2.z; r.inv[11] = v2.w;
+    r.p[0] = v3.x; r.p[1] = v3.y; r.p[2] = v3.z;
+    r.kind = __float_as_uint(v3.w);
+}
+// Second half: the way back to world space, parameters 3-5, the material.
+__device__ __forceinline__ void load_prim_rest(const PrimRec* prims, uint32_t i, PrimRegs& r) {
+    const float4* src = reinterpret_cast<const float4*>(prims + i) + 4;
+    const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+    r.fwd[0] = v0.x; r.fwd[1] = v0.y; r.fwd[2] = v0.z; r.fwd[3] = v0.w;
+    r.fwd[4] = v1.x; r.fwd[5] = v1.y; r.fwd[6] = v1.z; r.fwd[7] = v1.w;
+    r.fwd[8] = v2.x; r.fwd[9] = v2.y; r.fwd[10] = v2.z; r.fwd[11] = v2.w;
+    r.p[3] = v3.x; r.p[4] = v3.y; r.p[5] = v3.z;
+    r.material = __float_as_uint(v3.w);
+}
+__device__ __forceinline__ void load_prim(const PrimRec* prims, uint32_t i, PrimRegs& r) {
+    load_prim_test(prims, i, r);
+    load_prim_rest(prims, i, r);
 }
 
 // Object::hitRay (src/Object.cpp:22-33) for the analytic kinds: local ray (direction not
@@ -290,6 +298,33 @@ __device__ __forceinline__ bool hit_analytic(const PrimRegs& pr, const float* tr
     }
     if (!hit) return false;
     world = aff_pos(pr.fwd, lh);
+    t = dot(world - o, d);
+    return true;
+}
+
+// The same from the record in memory, in the two steps its layout is made for: the test reads the first half (four
+// 16-byte pieces), and only a lane that hits fetches the way back to world space (three more).
+__device__ __forceinline__ bool hit_analytic_from(const PrimRec* prims, const float* tri_c, uint32_t prim, f3 o, f3 d, f3& world, float& t) {
+    PrimRegs pr;
+    load_prim_test(prims, prim, pr);
+    const f3 lo = aff_pos(pr.inv, o);
+    const f3 ld = lin_mul(pr.inv, d);
+    f3 lh;
+    bool hit = false;
+    if (pr.kind == 0u) {
+        hit = hit_sphere(lo, ld, pr.p[0], lh);
+    } else if (pr.kind == 1u) {
+        hit = hit_rect(lo, ld, mk3(pr.p[0], pr.p[1], pr.p[2]), lh);
+    } else if (pr.kind == 2u) {
+        const float4 v = reinterpret_cast<const float4*>(prims + prim)[7];
+        const f3 c = mk3(tri_c[3 * prim], tri_c[3 * prim + 1], tri_c[3 * prim + 2]);
+        hit = hit_triangle(lo, ld, mk3(pr.p[0], pr.p[1], pr.p[2]), mk3(v.x, v.y, v.z), c, lh);
+    }
+    if (!hit) return false;
+    const float4* src = reinterpret_cast<const float4*>(prims + prim) + 4;
+    const float4 f0 = src[0], f1 = src[1], f2 = src[2];
+    const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
+    world = aff_pos(fwd, lh);
     t = dot(world - o, d);
     return true;
 }
@@ -441,6 +476,18 @@ __device__ __forceinline__ void trav_begin(Trav& t, f3 o, f3 d, uint32_t slot, b
 __device__ __forceinline__ bool trav_wants_inner(const Trav& t) { return t.busy && t.cur >= 0 && t.leaf == kTravNone; }
 __device__ __forceinline__ bool trav_wants_leaf(const Trav& t) { return t.busy && t.leaf != kTravNone; }
 __device__ __forceinline__ bool trav_finished(const Trav& t) { return t.busy && t.cur == kTravNone && t.leaf == kTravNone && t.sp == 0; }
+
+// A deferred child on the stack with the distance at which the ray enters its box: link in the upper 21 bits (node
+// index, or 2^20 + primitive for a leaf), the top 11 bits of the distance's float pattern -- sign (never set), exponent,
+// three bits of mantissa, i.e. rounded down by at most an eighth -- in the lower 11.  An entry whose distance lies
+// beyond the limit the ray has reached by the time it comes off the stack is dropped there and then: no node fetch, no
+// leaf-box fetch.  For trees of up to 2^20 nodes and 2^20 primitives (DIST); larger ones keep plain links and the leaf
+// boxes' re-test.
+constexpr uint32_t kEntryLeaf = 1u << 20;
+__device__ __forceinline__ int entry_pack(int c, float t) {
+    const uint32_t link = c >= 0 ? static_cast<uint32_t>(c) : (kEntryLeaf | static_cast<uint32_t>(~c));
+    return static_cast<int>((link << 11) | (__float_as_uint(t) >> 20));
+}
 
 // Nothing chosen: take entries off the stack until one is a node, or a leaf whose box the limit still reaches.
 __device__ __forceinline__ void trav_pop(const SceneDev& sc, Trav& t, const int* stack) {
@@ -650,18 +697,6 @@ __device__ __forceinline__ void pair_begin(PairRay& t, f3 o, f3 d, uint32_t slot
     t.slot = slot;
 }
 
-// A deferred child on the stack with the distance at which the ray enters its box: link in the upper 21 bits (node
-// index, or 2^20 + primitive for a leaf), the top 11 bits of the distance's float pattern -- sign (never set), exponent,
-// three bits of mantissa, i.e. rounded down by at most an eighth -- in the lower 11.  An entry whose distance lies
-// beyond the limit the ray has reached by the time it comes off the stack is dropped there and then: no node fetch, no
-// leaf-box fetch.  For trees of up to 2^20 nodes and 2^20 primitives (DIST); larger ones keep plain links and the leaf
-// boxes' re-test.
-constexpr uint32_t kEntryLeaf = 1u << 20;
-__device__ __forceinline__ int entry_pack(int c, float t) {
-    const uint32_t link = c >= 0 ? static_cast<uint32_t>(c) : (kEntryLeaf | static_cast<uint32_t>(~c));
-    return static_cast<int>((link << 11) | (__float_as_uint(t) >> 20));
-}
-
 template <int S, bool COUNT, bool DIST>
 __device__ __forceinline__ void trav_run_pair(const SceneDev& sc, const PathBuffers& pb, PairRay& r0, PairRay& r1, int* col, int rows, uint32_t keep_unfinished,
                                               TravCounts& counts, uint32_t leaf_quorum) {
@@ -743,11 +778,9 @@ __device__ __forceinline__ void trav_run_pair(const SceneDev& sc, const PathBuff
                 const uint32_t prim = static_cast<uint32_t>(~(l1 ? r1.next : r0.next));
                 const unsigned long long best = l1 ? r1.best : r0.best;
                 if (COUNT) ++counts.prims;
-                PrimRegs pr;
-                load_prim(sc.prims, prim, pr);
                 f3 w;
                 float th;
-                if (hit_analytic(pr, sc.tri_c, prim, o, d, w, th)) {
+                if (hit_analytic_from(sc.prims, sc.tri_c, prim, o, d, w, th)) {
                     const unsigned long long key = make_key(th, prim);
                     if (key < best) {
                         const float lim = fmaxf(th, 0.0f) * (1.0f / norm_sq(d)) * 1.00001f + 1e-6f;
@@ -1299,7 +1332,7 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
                 if (pr->kind == 4u) {
                     // FractalObject: the whole march here and now; p[0..5] hold its world box
                     f3 hp;
-                    if (fractal_march(lo, ld, mk3(pr->p[0], pr->p[1], pr->p[2]), mk3(pr->p[3], pr->p[4], pr->p[5]), hp)) {
+                    if (fractal_march(lo, ld, mk3(pr->p[0], pr->p[1], pr->p[2]), mk3(pr->q[0], pr->q[1], pr->q[2]), hp)) {
                         const f3 w = aff_pos(pr->fwd, hp);
                         const float t = dot(w - o, d);
                         const unsigned long long key = make_key(t, prim);
@@ -1314,8 +1347,8 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
                     continue;
                 }
                 off = mk3(pr->p[0], pr->p[1], pr->p[2]);
-                crater_base = __float_as_uint(pr->p[3]);
-                crater_count = __float_as_uint(pr->p[4]);
+                crater_base = __float_as_uint(pr->q[0]);
+                crater_count = __float_as_uint(pr->q[1]);
                 f3 box = ball_box;
                 if (PLAIN) {
                     plain = pr->kind >= 5u ? pr->kind : 0u;
@@ -1401,7 +1434,7 @@ __global__ void __launch_bounds__(256) k_sdf_eval(SceneDev sc, uint32_t prim, ui
     const PrimRec* pr = sc.prims + prim;
     const uint32_t kind = pr->kind;
     const f3 prm = mk3(pr->p[0], pr->p[1], pr->p[2]);
-    const uint32_t crater_base = __float_as_uint(pr->p[3]), crater_count = __float_as_uint(pr->p[4]);
+    const uint32_t crater_base = __float_as_uint(pr->q[0]), crater_count = __float_as_uint(pr->q[1]);
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounds = (n + stride - 1) / stride;   // every lane of a wave runs every round: wave_near is wave-wide
     uint32_t c_near = 0, c_noise = 0;
