@@ -1108,7 +1108,7 @@ template <int S, bool COUNT, bool DIST>
 __global__ void __launch_bounds__(256) k_extend_pair(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
     if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
     __shared__ int s_stack[S * 256];
-    constexpr uint32_t kCap = S <= 32 ? 256 : 128;   // four blocks share a CU's LDS up to S = 36
+    constexpr uint32_t kCap = S <= 32 ? 256 : 128;   // four blocks share a CU's LDS up to S = 38
     __shared__ uint32_t s_pend[4 * kCap];
     PendingQueue to_sdf{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u};
     const uint32_t n = pb.counters[bounce].n_live;
@@ -2029,9 +2029,9 @@ void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, co
     const bool dist = sc.n_prims <= (1u << 20) && sc.n_nodes <= (1u << 20) && !bp.pair_plain_entries;
     if (bp.trav_quorum_pair && stack_need > 8 && (dist || !count)) {
         // two rays per lane: one column of S entries for both (S >= the tree's need + 3: the second ray asks for three free rows before every visit, and must find them when it is alone)
-        if (stack_need + 3 <= 16) MIPT_LAUNCH_EXP(16);
-        else if (stack_need + 3 <= 32) MIPT_LAUNCH_EXP(32);
+        if (stack_need + 3 <= 32) MIPT_LAUNCH_EXP(32);
         else if (stack_need + 3 <= 36) MIPT_LAUNCH_EXP(36);
+        else if (stack_need + 3 <= 38) MIPT_LAUNCH_EXP(38);   // 38 KiB of stacks + 2 KiB of pending queue: the last size of which four blocks fit a CU
         else if (stack_need + 3 <= 40) MIPT_LAUNCH_EXP(40);
         else MIPT_LAUNCH_EXP(63);
         return;

@@ -44,6 +44,8 @@ for sc in random100k mixed20k random1m; do
   pmc sq_$N SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU -- $A
   pmc cache_$N TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum -- $A
   pmc fetch_$N FETCH_SIZE -- $A
+  # the vector-memory pipeline in front of the caches (address unit and L1 of every CU), what the traversal is bound by
+  pmc ta_$N TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_GATE_EN1_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum GRBM_GUI_ACTIVE -- $A
   bench_reads $OUT/r02_pmc_fetch_$N.csv
   timeout -k 10 400 python3 $R/bench.py $A --steps 3 --warmup 1 > $OUT/r02_bench_$N.json 2> /tmp/bench_$N.err
   echo "bench $N done"
