@@ -187,6 +187,14 @@ class Oracle(_Api):
         self.dll.orc_sdf_craterball(_fp(offset), _fp(noise), C.c_uint32(pos.shape[0]), _fp(pos), _fp(out))
         return out
 
+    def sdf_value(self, kind, params, noise, pos):
+        """signedDistance of the demo's RoughBoxObject (5), RoughSphereObject (6), WeirdWallObject (7) at local points."""
+        params, noise, pos = _f(params), _f(noise), _f(pos)
+        out = np.zeros(pos.shape[0], np.float32)
+        if not self.dll.orc_sdf_value(C.c_uint32(kind), _fp(params), _fp(noise), C.c_uint32(pos.shape[0]), _fp(pos), _fp(out)):
+            raise ValueError("no signed distance for kind %d" % kind)
+        return out
+
     def noise(self, noise, pos):
         noise, pos = _f(noise), _f(pos)
         out = np.zeros(pos.shape[0], np.float32)
@@ -340,6 +348,13 @@ class Reference(_Api):
         offset, pos = _f(offset), _f(pos)
         out = np.zeros(pos.shape[0], np.float32)
         self.dll.ref_sdf_craterball(_fp(offset), C.c_uint32(pos.shape[0]), _fp(pos), _fp(out))
+        return out
+
+    def sdf_value(self, kind, params, pos):
+        params, pos = _f(params), _f(pos)
+        out = np.zeros(pos.shape[0], np.float32)
+        if not self.has("ref_sdf_value") or not self.dll.ref_sdf_value(C.c_uint32(kind), _fp(params), C.c_uint32(pos.shape[0]), _fp(pos), _fp(out)):
+            return None
         return out
 
     def noise(self, pos):

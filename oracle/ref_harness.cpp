@@ -206,6 +206,21 @@ void ref_sdf_craterball(const float off[3], uint32_t n, const float* pos, float*
     for (uint32_t i = 0; i < n; ++i) out_d[i] = o.signedDistance(Pos(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]));
 }
 
+// signedDistance of the demo program's SDF classes (kinds 5-7: PathTracerDemo.cpp:237-246, 173-182, 281-328) at local points
+int ref_sdf_value(uint32_t kind, const float params[9], uint32_t n, const float* pos, float* out_d) {
+#ifdef DEMO_SDF_INC
+    const BasicMaterial m{};
+    auto eval = [&](const auto& o) {
+        for (uint32_t i = 0; i < n; ++i) out_d[i] = o.signedDistance(Pos(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]));
+    };
+    if (kind == 5) { eval(RoughBoxObject(Rectangle(Vec(params[0], params[1], params[2])), m)); return 1; }
+    if (kind == 6) { eval(RoughSphereObject(Sphere(params[0]), m, m)); return 1; }
+    if (kind == 7) { eval(WeirdWallObject(m)); return 1; }
+#endif
+    (void)kind; (void)params; (void)n; (void)pos; (void)out_d;
+    return 0;
+}
+
 void ref_camera_rays(const float cam16[16], uint32_t n, const float* sx, const float* sy, uint64_t seed,
                      float* out_dir, float* out_pos) {
     const auto cam = load_cam(cam16);

@@ -1118,6 +1118,19 @@ void orc_sdf_craterball(const float off[3], const float noise12[12], uint32_t n,
         out_d[i] = craterball_sdf(v3(off[0], off[1], off[2]), nt, v3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]), nullptr);
 }
 
+// signedDistance of the demo's RoughBoxObject (kind 5), RoughSphereObject (6) and WeirdWallObject (7) at local points
+int orc_sdf_value(uint32_t kind, const float params[9], const float noise12[12], uint32_t n, const float* pos, float* out_d) {
+    const Aff nt = load_aff(noise12);
+    for (uint32_t i = 0; i < n; ++i) {
+        const V3 p = v3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+        if (kind == ORC_ROUGHBOX) out_d[i] = roughbox_sdf(v3(params[0], params[1], params[2]), nt, p);
+        else if (kind == ORC_ROUGHSPHERE) out_d[i] = roughsphere_sdf(params[0], nt, p);
+        else if (kind == ORC_WEIRDWALL) out_d[i] = weirdwall_sdf(nt, p);
+        else return 0;
+    }
+    return 1;
+}
+
 void orc_noise(const float noise12[12], uint32_t n, const float* pos, float* out_v) {
     const Aff nt = load_aff(noise12);
     for (uint32_t i = 0; i < n; ++i) out_v[i] = fbm_noise(nt, v3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]));

@@ -111,6 +111,11 @@ def make_inputs():
     dd = _unit(np.stack([r.uniform(-0.3, 0.3, 200), r.uniform(-0.3, 0.3, 200), np.ones(200)], axis=1))
     o[:10] = np.stack([r.uniform(-3, 3, 10), r.uniform(-3, 2, 10), r.uniform(-0.5, 0.5, 10)], axis=1)   # origins near or inside the wall
     inp["ww_ray_pos"], inp["ww_ray_dir"] = o.astype(np.float32), dd.astype(np.float32)
+    # points at which the three classes' signedDistance is sampled directly: about the box and the sphere, and in the wall's near field
+    r = _rs(10)
+    inp["rb_sdf_pos"] = (r.uniform(-1.25, 1.25, (600, 3)) * inp["rb_half"]).astype(np.float32)
+    inp["rs_sdf_pos"] = (_unit(r.normal(size=(600, 3))) * r.uniform(0.6, 1.3, (600, 1))).astype(np.float32)
+    inp["ww_sdf_pos"] = np.stack([r.uniform(-4.5, 4.5, 600), r.uniform(-4.5, 3.6, 600), r.uniform(-0.9, 0.9, 600)], axis=1).astype(np.float32)
 
     # --- camera
     g = np.linspace(0, 1, 9, dtype=np.float32)
@@ -264,6 +269,9 @@ class RefBackend:
     def sdf(self, off, pos):
         return self.api.sdf_craterball(off, pos)
 
+    def sdf_value(self, kind, params, pos):
+        return self.api.sdf_value(kind, params, pos)
+
     def noise_fn(self, pos):
         return self.api.noise(pos)
 
@@ -324,6 +332,9 @@ class OracleBackend:
 
     def sdf(self, off, pos):
         return self.api.sdf_craterball(off, self.noise, pos)
+
+    def sdf_value(self, kind, params, pos):
+        return self.api.sdf_value(kind, params, self.noise, pos)
 
     def noise_fn(self, pos):
         return self.api.noise(self.noise, pos)
@@ -459,6 +470,7 @@ def evaluate(be, inp, heavy=True):
         hit, pos = be.hit_local(5, rp, inp["rb_ray_pos"], inp["rb_ray_dir"])
         out["rb_hit"], out["rb_hitpos"] = hit, pos
         out["rb_normal"] = be.normal_local(5, rp, pos[hit][:48])
+        out["rb_sdf"] = be.sdf_value(5, rp, inp["rb_sdf_pos"])
         rs = roughbox_scene(alg, be.noise)
         out["rb_bbox"] = api.world_bbox(5, rs.fwd[0], rp)
         sc = be.scene(rs)
@@ -473,6 +485,7 @@ def evaluate(be, inp, heavy=True):
             hit, pos = be.hit_local(kind, prm, inp[tag + "_ray_pos"], inp[tag + "_ray_dir"])
             out[tag + "_hit"], out[tag + "_hitpos"] = hit, pos
             out[tag + "_normal"] = be.normal_local(kind, prm, pos[hit][:32])
+            out[tag + "_sdf"] = be.sdf_value(kind, prm, inp[tag + "_sdf_pos"])
             fs = mk(alg, be.noise)
             out[tag + "_bbox"] = api.world_bbox(kind, fs.fwd[0], prm)
             sc = be.scene(fs)

@@ -145,6 +145,46 @@ def test_craterball_sdf_values_against_the_restatement(alg, oracle):
     assert np.abs(want[near]).max() < 0.35 and want[near].std() > 0.02
 
 
+# RoughBoxObject is +, -, *, sqrt, floor, min, max in the reference's order: its device values are the restatement's bit for bit.
+# RoughSphereObject and WeirdWallObject call exp2 / log2 / exp / hypot / atan2, whose device versions differ from the host
+# library's in the last bits.  Measured on 120,000 points each when the bounds were set (the test prints the figures): rough sphere
+# max |err| 1.19e-7 (one unit in the last place of values near 1; 74 % of the values bit-identical), weird wall max 6.4e-7, 99.9th
+# percentile 2.4e-7 (68 % bit-identical).  Bounds: twice that.
+PLAIN_SDF_BOUNDS = {6: (2.4e-7, 2.4e-7), 7: (1.3e-6, 4.8e-7)}   # kind: (max |err|, 99.9th percentile)
+
+
+@pytest.mark.parametrize("kind", [5, 6, 7])
+def test_demo_sdf_class_values_against_the_restatement(kind, ctx, alg, oracle):
+    """signedDistance of the demo's RoughBoxObject (PathTracerDemo.cpp:237-246), RoughSphereObject (:173-182) and WeirdWallObject
+    (:281-328) on the device (mipt_sdf_eval: the function the march and the normals call) against the restatement, whose
+    values the reference's own classes pin bit for bit (fixtures rb_sdf, rs_sdf, ww_sdf)."""
+    z = np.load(FIXTURE, allow_pickle=False)
+    noise = z["out_noise12"]
+    r = np.random.RandomState(100 + kind)
+    n = 120_000
+    if kind == 5:
+        flat, prm = G.roughbox_scene(alg, noise), np.array([0.5, 0.4, 0.6] + [0.0] * 6, np.float32)
+        p = r.uniform(-1.25, 1.25, (n, 3)) * prm[:3]
+    elif kind == 6:
+        flat, prm = G.roughsphere_scene(alg, noise), np.array([1.0] + [0.0] * 8, np.float32)
+        p = _unit(r.normal(size=(n, 3))) * r.uniform(0.5, 1.3, (n, 1))
+    else:
+        flat, prm = G.weirdwall_scene(alg, noise), np.zeros(9, np.float32)
+        p = np.stack([r.uniform(-5.0, 5.0, n), r.uniform(-4.6, 3.8, n), r.uniform(-1.2, 1.2, n)], axis=1)
+    p = p.astype(np.float32)
+    assert int(flat.kind[0]) == kind
+    want = oracle.sdf_value(kind, prm, noise, p)
+    got = ctx.sdf_eval(ctx.upload(flat), 0, p)
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    print(f"kind {kind}: {n} points, values in [{want.min():.3f}, {want.max():.3f}], max |err| = {err.max():.3e}, "
+          f"99.9th percentile = {np.percentile(err, 99.9):.3e}, mean = {err.mean():.3e}, bit-identical: {(got == want).mean():.4f}")
+    assert want.std() > 0.005 and (want < 0).mean() > 0.02 and (want > 0).mean() > 0.02    # the points straddle the surface
+    if kind == 5:
+        assert np.array_equal(got, want)
+    else:
+        assert err.max() <= PLAIN_SDF_BOUNDS[kind][0] and np.percentile(err, 99.9) <= PLAIN_SDF_BOUNDS[kind][1]
+
+
 # Measured when the bounds were set, 65,536 pixels per view.  Demo camera: 0 pixels disagree on hit / miss, 534 common
 # hits, max |dt| 5.5e-5.  Close-up: 1 pixel disagrees, 31,335 common hits, 99.9th percentile of |dt| 9.9e-5 (the march stops
 # within 1e-4 of the surface, so two marches whose SDF values differ in the last bits may stop one step apart), max |dt|
