@@ -59,7 +59,7 @@ struct mipt_ctx {
     bool pair_plain = false;   // MIPT_PAIR_PLAIN=1 (test aid): stack entries carry no entry distance, as in trees too large for the packed form
     bool pair_tight = false;   // MIPT_PAIR_TIGHT=1 (test aid): the two rays of a lane share only as many stack rows as one ray can need (+ 3), so the second ray starts over often
     uint32_t trav_quorum_pair = 32, trav_keep_pair = 76;   // MIPT_PAIR_QUORUM (0: one ray per lane), MIPT_PAIR_KEEP: the same with two rays per lane
-    uint32_t trav_quorum = 20, trav_quorum_primary = 2, trav_keep = 40;   // MIPT_LEAF_QUORUM, MIPT_LEAF_QUORUM_PRIMARY, MIPT_KEEP_BUSY: scheduling of the BVH traversal's two phases (tuning aids)
+    uint32_t trav_quorum = 20, trav_quorum_primary = 1, trav_keep = 40;   // MIPT_LEAF_QUORUM, MIPT_LEAF_QUORUM_PRIMARY, MIPT_KEEP_BUSY: scheduling of the BVH traversal's two phases (tuning aids)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // optional per-launch timing

@@ -50,7 +50,7 @@ struct BatchParams {
     uint32_t flags;
     uint32_t lane_threshold;   // SDF near field: waiting lanes from which a wave evaluates one point per lane
     uint32_t trav_quorum;      // BVH traversal: lanes with a pending leaf from which a wave runs a leaf step (20)
-    uint32_t trav_quorum_primary;   // the same for camera rays, whose waves hold neighbouring pixels and reach their leaves together (2)
+    uint32_t trav_quorum_primary;   // the same for camera rays, whose waves hold neighbouring pixels and reach their leaves together (1)
     uint32_t trav_keep;        // BVH traversal: a wave refills its idle lanes when fewer than trav_keep / 64 of its busy lanes are unfinished (40)
     uint32_t trav_quorum_pair;   // two rays per lane (0: one ray per lane): lanes with a pending leaf from which a wave runs a leaf step
     uint32_t trav_keep_pair;     // ... and a wave turns its finished rays over when fewer than trav_keep_pair / 128 of its rays are unfinished
