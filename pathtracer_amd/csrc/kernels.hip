@@ -477,16 +477,14 @@ __device__ __forceinline__ bool trav_wants_inner(const Trav& t) { return t.busy 
 __device__ __forceinline__ bool trav_wants_leaf(const Trav& t) { return t.busy && t.leaf != kTravNone; }
 __device__ __forceinline__ bool trav_finished(const Trav& t) { return t.busy && t.cur == kTravNone && t.leaf == kTravNone && t.sp == 0; }
 
-// A deferred child on the stack with the distance at which the ray enters its box: link in the upper 21 bits (node
-// index, or 2^20 + primitive for a leaf), the top 11 bits of the distance's float pattern -- sign (never set), exponent,
-// three bits of mantissa, i.e. rounded down by at most an eighth -- in the lower 11.  An entry whose distance lies
-// beyond the limit the ray has reached by the time it comes off the stack is dropped there and then: no node fetch, no
-// leaf-box fetch.  For trees of up to 2^20 nodes and 2^20 primitives (DIST); larger ones keep plain links and the leaf
-// boxes' re-test.
-constexpr uint32_t kEntryLeaf = 1u << 20;
+// A deferred child on the stack with the distance at which the ray enters its box: the link as the tree stores it
+// (node index, or ~primitive for a leaf) shifted up by 11 bits, the top 11 bits of the distance's float pattern below it
+// -- sign (never set), exponent, three bits of mantissa, i.e. rounded down by at most an eighth.  An arithmetic shift
+// gives the link back, sign and all.  An entry whose distance lies beyond the limit the ray has reached by the time it
+// comes off the stack is dropped there and then: no node fetch, no leaf-box fetch.  For trees of up to 2^20 nodes and
+// 2^20 primitives (DIST): links then fit 21 signed bits; larger ones keep plain links and the leaf boxes' re-test.
 __device__ __forceinline__ int entry_pack(int c, float t) {
-    const uint32_t link = c >= 0 ? static_cast<uint32_t>(c) : (kEntryLeaf | static_cast<uint32_t>(~c));
-    return static_cast<int>((link << 11) | (__float_as_uint(t) >> 20));
+    return static_cast<int>((static_cast<uint32_t>(c) << 11) | (__float_as_uint(t) >> 20));
 }
 
 // Nothing chosen: take entries off the stack until one is a node, or a leaf whose box the limit still reaches.
@@ -726,10 +724,8 @@ __device__ __forceinline__ void trav_run_pair(const SceneDev& sc, const PathBuff
                 p -= step;
                 const int e = *p;
                 if (DIST) {
-                    const uint32_t u = static_cast<uint32_t>(e);
-                    if (((u & 0x7ffu) << 20) > __float_as_uint(limit)) continue;   // entered beyond the limit (both patterns are of non-negative floats)
-                    const uint32_t link = u >> 11;
-                    next = (link & kEntryLeaf) ? ~static_cast<int>(link & (kEntryLeaf - 1u)) : static_cast<int>(link);
+                    if (((static_cast<uint32_t>(e) & 0x7ffu) << 20) > __float_as_uint(limit)) continue;   // entered beyond the limit (both patterns are of non-negative floats)
+                    next = e >> 11;   // arithmetic: a leaf's link stays negative
                 } else if (e >= 0) {
                     next = e;
                 } else {
