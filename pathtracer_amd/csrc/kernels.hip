@@ -2001,6 +2001,7 @@ void launch_generate_extend(hipStream_t st, const CameraRec& cam, const SceneDev
     if (stack_need <= 8) MIPT_LAUNCH_GE(8, 1024);
     else if (stack_need <= 24) MIPT_LAUNCH_GE(24, 512);
     else if (stack_need <= 32) MIPT_LAUNCH_GE(32, 256);
+    else if (stack_need <= 36) MIPT_LAUNCH_GE(36, 128);   // 36 + 4 KiB: the last size of which four blocks fit a CU (the 1M-object tree needs 35)
     else if (stack_need <= 48) MIPT_LAUNCH_GE(48, 128);
     else MIPT_LAUNCH_GE(60, 128);
 #undef MIPT_LAUNCH_GE

@@ -118,11 +118,12 @@ def test_deep_trees_walk_with_the_deep_stacks(ctx, alg, oracle):
         assert close.mean() >= 0.995, close.mean()
     print(f"chain of {n} spheres: tree depth {depths[0]} (host build), {depths[1]} (device build)")
     assert (wp >= 0).mean() > 0.8
-    # every instantiation of the traversal kernels (stacks of 8, 24, 32, 48 and 60 entries) on one scene: identical frames
+    # every instantiation of the traversal kernels on one scene (one ray per lane: stacks of 8, 24, 32, 36, 48 and 60 entries;
+    # two rays per lane: shared columns of 32, 36, 38, 40 and 63 rows): identical frames
     flat = S.random_scene(alg, 40, seed=4, radius_scale=12.0, glass_mirror_mix=True)
     cam = S.random_scene_camera(alg, aspect=1.0)
     frames = []
-    for need in ("0", "20", "30", "40", "60"):
+    for need in ("0", "20", "30", "34", "37", "40", "60"):
         os.environ["MIPT_MIN_STACK"] = need
         try:
             c = api.Context()
