@@ -1033,7 +1033,8 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
     hipError_t e = upload(&s->d_prims, prims.data(), prims.size() * sizeof(PrimRec));
     if (e == hipSuccess) e = upload(&s->d_tri, tri_c.data(), tri_c.size() * sizeof(float));
     if (e == hipSuccess) e = upload(&s->d_mats, mats.data(), mats.size() * sizeof(MaterialRec));
-    std::vector<Bvh4QNode> qnodes = quantize_bvh4(bvh4.nodes);   // the 64-byte form the kernels read
+    std::vector<Bvh4QNode> qnodes(bvh4.nodes.size());   // the 64-byte form the kernels read
+    host_parallel_for(static_cast<uint32_t>(qnodes.size()), [&](uint32_t i) { quantize_bvh4_node(bvh4.nodes[i], qnodes[i]); });
     if (const char* nc = std::getenv("MIPT_NO_CULL"); nc && std::atoi(nc) != 0) {
         // test aid: every box of the tree becomes all of space, so that every ray visits every node and tests every
         // primitive -- the reference's own rule (src/ObjectTree.cpp:22-88 never culls) through the same kernels; a frame

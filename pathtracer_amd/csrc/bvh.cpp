@@ -282,12 +282,9 @@ Bvh4Result collapse_bvh4(const BvhNode* nodes2, size_t n_nodes2, uint32_t n_prim
 
 float bvh4q_plane(const Bvh4QNode& n, int axis, uint32_t q) { return std::fmaf(static_cast<float>(q), n.scale[axis], n.org[axis]); }
 
-std::vector<Bvh4QNode> quantize_bvh4(const std::vector<Bvh4Node>& nodes) {
-    std::vector<Bvh4QNode> out(nodes.size());
+void quantize_bvh4_node(const Bvh4Node& n, Bvh4QNode& q) {
     const float inf = std::numeric_limits<float>::infinity();
-    for (size_t i = 0; i < nodes.size(); ++i) {
-        const Bvh4Node& n = nodes[i];
-        Bvh4QNode& q = out[i];
+    {
         const float* lo[3] = {n.lox, n.loy, n.loz};
         const float* hi[3] = {n.hix, n.hiy, n.hiz};
         for (int a = 0; a < 3; ++a) {
@@ -324,6 +321,11 @@ std::vector<Bvh4QNode> quantize_bvh4(const std::vector<Bvh4Node>& nodes) {
         }
         for (int k = 0; k < 4; ++k) q.child[k] = n.child[k];
     }
+}
+
+std::vector<Bvh4QNode> quantize_bvh4(const std::vector<Bvh4Node>& nodes) {
+    std::vector<Bvh4QNode> out(nodes.size());
+    for (size_t i = 0; i < nodes.size(); ++i) quantize_bvh4_node(nodes[i], out[i]);
     return out;
 }
 

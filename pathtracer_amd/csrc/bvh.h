@@ -40,6 +40,7 @@ Bvh4Result collapse_bvh4(const BvhNode* nodes2, size_t n_nodes2, uint32_t n_prim
 
 // The 64-byte form of the four-child nodes (same indices, same links): every decoded child box contains the original.
 std::vector<Bvh4QNode> quantize_bvh4(const std::vector<Bvh4Node>& nodes);
+void quantize_bvh4_node(const Bvh4Node& node, Bvh4QNode& out);   // one node (nodes are independent: callers may spread them over threads)
 // plane = org + scale * q as the quantiser guarantees it (one fused multiply-add)
 float bvh4q_plane(const Bvh4QNode& n, int axis, uint32_t q);
 
