@@ -140,6 +140,11 @@ typedef struct {
     uint64_t trav_rounds;
     uint64_t trav_leaf_steps;
     uint64_t trav_restarts;
+    /* SDF marches (include/Object.hpp:135-167) that one bounce's launch handed to the next one's instead of finishing
+     * them: the longest marches of a launch would otherwise hold the whole chip for a few lanes' sake.  Such a path
+     * runs one launch behind the others from then on; its samples and random numbers are its own, so the frame does
+     * not change.  MIPT_CARRY_LAG=0 turns it off. */
+    uint64_t marches_carried;
 } mipt_stats;
 
 enum { MIPT_STAGE_GENERATE = 0, MIPT_STAGE_EXTEND = 1, MIPT_STAGE_SDF_MARCH = 2, MIPT_STAGE_SHADE = 3,

@@ -163,7 +163,8 @@ class Context:
                     primary_traced=int(st.primary_traced), samples_done=int(st.samples_done),
                     node_visits=int(st.node_visits), prim_tests=int(st.prim_tests),
                     host_rays=int(st.host_rays), host_shades=int(st.host_shades),
-                    trav_rounds=int(st.trav_rounds), trav_leaf_steps=int(st.trav_leaf_steps), trav_restarts=int(st.trav_restarts))
+                    trav_rounds=int(st.trav_rounds), trav_leaf_steps=int(st.trav_leaf_steps), trav_restarts=int(st.trav_restarts),
+                    marches_carried=int(st.marches_carried))
 
     def render(self, scene, cam16, w, h, bounces, spp, seed=1, first_sample=0, flags=0):
         """Renderer::render: (h, w, 3) float32 mean image and the call's statistics."""

@@ -48,7 +48,8 @@ class Stats(C.Structure):
                 ("primary_traced", C.c_uint64), ("samples_done", C.c_uint64),
                 ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64),
                 ("host_rays", C.c_uint64), ("host_shades", C.c_uint64),
-                ("trav_rounds", C.c_uint64), ("trav_leaf_steps", C.c_uint64), ("trav_restarts", C.c_uint64)]
+                ("trav_rounds", C.c_uint64), ("trav_leaf_steps", C.c_uint64), ("trav_restarts", C.c_uint64),
+                ("marches_carried", C.c_uint64)]
 
 
 HIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, _f32p, _f32p, _f32p)

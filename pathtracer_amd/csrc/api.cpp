@@ -55,6 +55,10 @@ struct mipt_ctx {
     bool device_bvh = false;        // MIPT_DEVICE_BVH=1: mipt_scene_upload builds the tree on the GPU
     bool full_march = false;        // MIPT_FULL_MARCH=1: no shortcut for SDF marches that cannot end (for the equivalence test)
     uint32_t lane_threshold = 14;   // MIPT_LANE_THRESHOLD: 1 = always one point per lane, 65 = never
+    // MIPT_CARRY_LAG (0: off), MIPT_CARRY_AFTER: SDF marches still running when a launch's queue is handed out go to the next
+    // round's launch (BatchParams::carry_max_lag, carry_after)
+    uint32_t carry_lag = 4, carry_after = 32;
+    uint32_t carry_cap = 0;         // records in each of the two hand-over buffers of the arena
     int min_stack = 0;   // MIPT_MIN_STACK: the traversal kernels are picked as if every tree needed at least this many stack entries (a test aid)
     bool pair_plain = false;   // MIPT_PAIR_PLAIN=1 (test aid): stack entries carry no entry distance, as in trees too large for the packed form
     bool pair_tight = false;   // MIPT_PAIR_TIGHT=1 (test aid): the two rays of a lane share only as many stack rows as one ray can need (+ 3), so the second ray starts over often
@@ -119,6 +123,9 @@ constexpr size_t slot_bytes() {
     return b;
 }
 constexpr size_t kMaxSlots = (size_t(1) << 31) - 256;      // slot indices are 32-bit
+// Marches a launch can hand to the next (64 bytes each, two buffers): what the waves resident at a launch's end can
+// hold, 3,072 waves x 64 lanes, with room to spare.  Marches beyond that are finished where they are.
+constexpr size_t kCarryRecords = size_t(1) << 18;
 constexpr size_t kDefaultArenaCeiling = size_t(48) << 30;  // bytes; MIPT_BATCH_PATHS asks for more
 
 // Paths in flight per sample batch.  Every bounce of every batch ends in a latency-bound tail (the longest SDF
@@ -163,10 +170,12 @@ int ensure_slots(mipt_ctx* c, size_t slots, size_t words) {
     for (int k = 0; k < 10; ++k) o_arr[k] = take(n * kSlotArrayBytes[k]);
     const size_t o_ro = o_arr[0], o_rd = o_arr[1], o_att = o_arr[2], o_rad = o_arr[3], o_key = o_arr[4], o_pos = o_arr[5];
     const size_t o_q0 = o_arr[6], o_q1 = o_arr[7], o_qs = o_arr[8], o_qss = o_arr[9];
-    const size_t o_cnt = take(sizeof(BounceCounters) * (kMaxBounces + 1));
+    const size_t o_cnt = take(sizeof(BounceCounters) * kCounterRows);
     const size_t o_tot = take(sizeof(Totals));
     const size_t o_bits = take(words * 8);
     const size_t o_latch = take(sizeof(uint32_t));
+    const size_t carry_cap = std::min<size_t>(n, kCarryRecords);
+    const size_t o_carry0 = take(carry_cap * sizeof(CarryRec)), o_carry1 = take(carry_cap * sizeof(CarryRec));
     void* base = nullptr;
     const hipError_t e = hipMalloc(&base, off);
     if (e != hipSuccess) {
@@ -191,6 +200,9 @@ int ensure_slots(mipt_ctx* c, size_t slots, size_t words) {
     c->pb.live_bits = reinterpret_cast<unsigned long long*>(b + o_bits);
     c->pb.cancel = c->cancel_dev;
     c->pb.cancel_latch = reinterpret_cast<uint32_t*>(b + o_latch);
+    c->pb.carry[0] = reinterpret_cast<CarryRec*>(b + o_carry0);
+    c->pb.carry[1] = reinterpret_cast<CarryRec*>(b + o_carry1);
+    c->carry_cap = static_cast<uint32_t>(carry_cap);
     c->bits_cap = words;
     return MIPT_OK;
 }
@@ -473,7 +485,10 @@ int enqueue_bounces(mipt_ctx* c, const mipt_scene* sc, const BatchParams& bp, ui
     Totals local{};
     Totals& ht = host_totals ? *host_totals : local;
     const bool host = !sc->host_prims.empty();
-    for (uint32_t b = 0; b < bounces; ++b) {
+    // Paths whose SDF march was handed on run behind the others; the rounds after the last bounce are theirs
+    // (every kernel returns at once on an empty queue).
+    const uint32_t rounds = bounces + bp.carry_max_lag;
+    for (uint32_t b = 0; b < rounds; ++b) {
         const int done = b == 0 ? first_done : 0;
         if (b > 0) launch_latch_cancel(c->stream, c->pb);
         if (done < 1) { StageTimer t(c, MIPT_STAGE_EXTEND); launch_extend(c->stream, sc->dev, bp, c->pb, b, std::max(sc->stack_need, c->min_stack), c->counting); }
@@ -491,7 +506,7 @@ int enqueue_bounces(mipt_ctx* c, const mipt_scene* sc, const BatchParams& bp, ui
     }
     // every real path casts a primary ray (tile padding does not)
     const uint32_t primaries = bp.tiles_x ? bp.width * bp.height * (bp.n_slots / bp.n_pix) : bp.n_slots;
-    launch_finish_batch(c->stream, c->pb, bounces, primaries);
+    launch_finish_batch(c->stream, c->pb, rounds, primaries, bp.carry_cap);
     return MIPT_OK;
 }
 
@@ -619,6 +634,10 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.first_sample = st->first_sample + done;
         bp.flags = (st->flags & static_cast<uint32_t>(MIPT_FLAG_NO_JITTER)) | (c->full_march ? kFlagFullMarch : 0u);
         bp.lane_threshold = c->lane_threshold;
+        // marches are handed on only where nothing synchronises with the host inside a batch
+        bp.carry_max_lag = (sc->n_sdf && sc->host_prims.empty()) ? std::min<uint32_t>(c->carry_lag, kCounterRows - 1 - st->bounces) : 0u;
+        bp.carry_after = c->carry_after;
+        bp.carry_cap = c->carry_cap;
     bp.trav_quorum = c->trav_quorum;
     bp.trav_quorum_primary = c->trav_quorum_primary;
     bp.trav_keep = c->trav_keep;
@@ -627,7 +646,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
     bp.pair_plain_entries = c->pair_plain ? 1u : 0u;
     bp.pair_rows = c->pair_tight ? static_cast<uint32_t>(std::max(sc->stack_need, c->min_stack)) + 3u : 0u;
         bp.seed = st->seed;
-        HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * kCounterRows, c->stream));
         launch_latch_cancel(c->stream, c->pb);
         { StageTimer t(c, MIPT_STAGE_GENERATE); launch_generate_extend(c->stream, cr, sc->dev, bp, c->pb, cull, std::max(sc->stack_need, c->min_stack), c->counting); }
         if (const int rb = enqueue_bounces(c, sc, bp, st->bounces, 1, &host_totals); rb != MIPT_OK) return rb;
@@ -663,6 +682,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         stats->trav_rounds = t.trav_rounds;
         stats->trav_leaf_steps = t.trav_leaf_steps;
         stats->trav_restarts = t.trav_restarts;
+        stats->marches_carried = t.marches_carried;
         stats->host_rays = host_totals.host_rays;
         stats->host_shades = host_totals.host_shades;
         stats->ms_device = ms;
@@ -732,6 +752,8 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
         c->cancel_dev = static_cast<const volatile uint32_t*>(dev);
     }
     if (const char* e = std::getenv("MIPT_FULL_MARCH")) c->full_march = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_CARRY_LAG")) c->carry_lag = static_cast<uint32_t>(std::min(long(kMaxCarryLag), std::max(0L, std::atol(e))));
+    if (const char* e = std::getenv("MIPT_CARRY_AFTER")) c->carry_after = static_cast<uint32_t>(std::min(100000L, std::max(0L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_DEVICE_BVH")) c->device_bvh = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_LEAF_QUORUM")) c->trav_quorum = static_cast<uint32_t>(std::min(64L, std::max(1L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_LEAF_QUORUM_PRIMARY")) c->trav_quorum_primary = static_cast<uint32_t>(std::min(64L, std::max(1L, std::atol(e))));
@@ -1336,7 +1358,7 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     bp.pair_rows = c->pair_tight ? static_cast<uint32_t>(std::max(sc->stack_need, c->min_stack)) + 3u : 0u;
     mipt_camera c0 = *cam;
     c0.blur_radius = 0.0f;
-    HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * kCounterRows, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->pb.hit_key, 0xff, n * 8, c->stream));   // the fused kernel stores hits only
     launch_latch_cancel(c->stream, c->pb);
     launch_generate_extend(c->stream, pack_camera(c0), sc->dev, bp, c->pb, screen_rects(sc, c0, width, height), std::max(sc->stack_need, c->min_stack));
@@ -1394,7 +1416,7 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     bp.pair_rows = c->pair_tight ? static_cast<uint32_t>(std::max(sc->stack_need, c->min_stack)) + 3u : 0u;
     bp.flags = c->full_march ? kFlagFullMarch : 0u;
     bp.seed = seed;
-    HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * (kMaxBounces + 1), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->pb.counters, 0, sizeof(BounceCounters) * kCounterRows, c->stream));
     launch_latch_cancel(c->stream, c->pb);
     launch_load_rays(c->stream, c->stage, c->stage + static_cast<size_t>(n) * 3, n, c->pb);
     std::vector<unsigned long long> keys;

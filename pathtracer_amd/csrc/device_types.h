@@ -123,13 +123,33 @@ struct SceneDev {
 struct BounceCounters {
     uint32_t n_live;        // entries in the path queue feeding this bounce (bounce > 0)
     uint32_t n_sdf;         // rays queued for the SDF march
-    uint32_t sdf_head;      // work-fetch cursor of the SDF march
+    uint32_t sdf_head;      // (unused)
     uint32_t n_sdf_shade;   // hits queued for SDF shading
     uint32_t extend_head[8];   // work-fetch cursors of extend, one per XCD
     uint32_t n_host_rays;   // rays gathered for one host object (reset per object)
     uint32_t n_host_shade;  // hits on host objects queued for shading on the host
-    uint32_t pad[2];
+    uint32_t n_carry;       // SDF marches this round's launch left unfinished for the next round's (may exceed the buffer: readers clamp)
+    uint32_t n_late;        // rays of earlier rounds whose handed-on march this round's launch finished (they joined n_live)
+    uint32_t pad2[12];
+    // work-fetch cursors of the SDF march (kMarchCursors), each on a cache line of its own: atomics on one line are served one at a time
+    uint32_t sdf_heads[16][32];
 };
+
+// An SDF march that its launch handed on to the next round's launch instead of finishing it (k_sdf_march): everything
+// of the lane's state that cannot be read back from the path's slot.  64 bytes.
+struct alignas(16) CarryRec {
+    uint32_t slot;
+    uint32_t k;                 // index into SceneDev::sdf_boxes of the primitive being marched
+    uint32_t best_lo, best_hi;  // the ray's best hit key so far (the slot's own key holds kCarriedKey meanwhile)
+    float p[3];                 // March::p
+    float d;                    // March::d
+    float seen_p[3];            // March::seen_p
+    float seen_d;
+    uint32_t iter_flags;        // March::iter | first << 16 | sign << 17
+    uint32_t since, span;
+    uint32_t pad;
+};
+static_assert(sizeof(CarryRec) == 64, "CarryRec must be 64 bytes");
 
 struct Totals {
     unsigned long long rays, sdf_rays, sdf_shades;
@@ -140,8 +160,13 @@ struct Totals {
     unsigned long long host_rays, host_shades;                           // work handed to the host for objects without a device form
     unsigned long long trav_rounds, trav_leaf_steps, trav_restarts;     // counting build of k_extend_pair: wave rounds, leaf steps, second rays started over
     unsigned long long samples_done;                                     // samples per pixel that entered the frame (batches accumulated before a cancel)
+    unsigned long long marches_carried;                                  // SDF marches handed from one round's launch to the next
 };
 
 constexpr int kMaxBounces = 64;
+// A path whose march was handed on falls one round behind the others; it may do so this many times, and a batch
+// runs that many rounds after the last bounce for the paths that did.
+constexpr int kMaxCarryLag = 8;
+constexpr int kCounterRows = kMaxBounces + kMaxCarryLag + 1;
 
 }   // namespace mipt

@@ -20,7 +20,9 @@ struct PathBuffers {
     uint32_t* sdf_queue;  // slots whose ray entered an SDF primitive's box
     uint32_t* sdf_shade_queue;   // slots whose closest hit is an SDF primitive
     uint32_t* host_queue;        // slots handed to the host (rays that reach a host object's box; hits on host objects); null without host objects
-    BounceCounters* counters;    // kMaxBounces + 1 entries
+    BounceCounters* counters;    // kCounterRows entries, one per round of the batch
+    // SDF marches handed from one round's march launch to the next one's, ping-pong by round (null: never hand on)
+    CarryRec* carry[2];
     Totals* totals;
     // one bit per slot, set for the paths whose primary ray hit something or reached an SDF box (only
     // those ever carry radiance); sample s of pixel p is bit p & 63 of word s * ceil(n_pix / 64) + p / 64
@@ -56,6 +58,10 @@ struct BatchParams {
     uint32_t trav_keep_pair;     // ... and a wave turns its finished rays over when fewer than trav_keep_pair / 128 of its rays are unfinished
     uint32_t pair_plain_entries; // test aid: stack entries without entry distances, as trees beyond 2^20 nodes or primitives get them
     uint32_t pair_rows;          // test aid: rows of the shared stack column in use (0: all; at least the tree's need + 3)
+    // SDF marches still running when a wave has no more rays to fetch are handed to the next round's launch once the
+    // wave has gone carry_after more rounds, if their path has fallen behind fewer than carry_max_lag times (0: every
+    // launch finishes its marches) and the buffer of carry_cap records has room.
+    uint32_t carry_max_lag, carry_after, carry_cap;
     uint64_t seed;
 };
 
@@ -77,7 +83,7 @@ void launch_generate_extend(hipStream_t, const CameraRec&, const SceneDev&, cons
 void launch_extend(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, int stack_need, bool count = false);
 // big-crater candidates of a crater ball: 12 floats per cell of the n^3 lattice cube at `base` (x-major)
 void launch_crater_cells(hipStream_t, const float off[3], const int base[3], int n, float* out);
-void launch_sdf_march(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce);
+void launch_sdf_march(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t round);
 // signed distance of SDF primitive `prim` at n points of its local frame (device arrays)
 void launch_sdf_eval(hipStream_t, const SceneDev&, uint32_t prim, uint32_t lane_threshold, const float* pos3, uint32_t n, float* out);
 void launch_shade(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, uint32_t max_bounces);
@@ -93,7 +99,7 @@ void launch_host_merge(hipStream_t, const PathBuffers&, uint32_t n, const uint32
 void launch_host_export_hits(hipStream_t, const PathBuffers&, uint32_t n, float* out6, uint32_t* out_prim);
 // applies the host's bounces (9 floats per entry: emitted, attenuation, world direction) to the first n slots of host_queue
 void launch_host_apply(hipStream_t, const PathBuffers&, uint32_t n, const float* bounce9, uint32_t bounce, uint32_t max_bounces);
-void launch_finish_batch(hipStream_t, const PathBuffers&, uint32_t bounces, uint32_t n_slots);
+void launch_finish_batch(hipStream_t, const PathBuffers&, uint32_t rounds, uint32_t n_slots, uint32_t carry_cap);
 // frame[pix] += sum over the batch's samples, in sample order (the `acc +=` of src/Renderer.cpp:97-99)
 void launch_latch_cancel(hipStream_t, const PathBuffers&);
 void launch_accumulate(hipStream_t, const BatchParams&, const PathBuffers&, float* frame_sum);

@@ -89,6 +89,9 @@ __device__ __forceinline__ unsigned long long make_key(float t, uint32_t prim) {
     return (static_cast<unsigned long long>(ordered_bits(t)) << 32) | prim;
 }
 constexpr unsigned long long kMissKey = ~0ull;
+// In a slot's hit key while the path's SDF march waits for the next round's launch (k_sdf_march): the closest hit is
+// not known yet, shading passes the path by.  (No hit has this key: its distance field is a NaN's.)
+constexpr unsigned long long kCarriedKey = ~0ull - 1ull;
 
 // ---- analytic intersections (src/Geometry.cpp) -------------------------------------------------
 constexpr float kGeoEps = 1e-3f;   // :8
@@ -907,6 +910,70 @@ __device__ __forceinline__ bool cursor_take(QueueCursor& q, bool want, uint32_t*
     return have;
 }
 
+// The same over sixteen cursors.  Towards the end of a queue the chunks shrink to what a wave's idle lanes need, one
+// atomic per wave and round; on a single address the chip serves those one at a time (tens of nanoseconds each), and
+// three thousand waves then wait for their turn instead of marching: a fixed millisecond or two per launch, whatever
+// its length.  Entries are dealt to the cursors in blocks of 256 (block b belongs to cursor b mod 16, so every cursor
+// starts with some of the queue's first entries, and a full chunk is still 256 neighbours of the queue: rays of
+// neighbouring pixels, which walk the same craters); a wave starts on the cursor of its workgroup and moves on when
+// that one is handed out.  Which wave processes which entry never matters for the result.
+#ifndef MIPT_MARCH_CURSORS
+#define MIPT_MARCH_CURSORS 16
+#endif
+constexpr uint32_t kMarchCursors = MIPT_MARCH_CURSORS;
+struct SplitCursor {
+    uint32_t next, end;         // wave-uniform: reserved range, in the current cursor's own numbering
+    uint32_t cur, tried;        // cursor in use, cursors found handed out
+};
+__device__ __forceinline__ bool split_empty(const SplitCursor& q) { return q.tried >= kMarchCursors && q.next >= q.end; }
+// All 64 lanes call; lanes with `want` get an entry index in `i` (returns whether they did).
+__device__ __forceinline__ bool split_take(SplitCursor& q, bool want, uint32_t (*heads)[32], uint32_t n, uint32_t n_waves, uint32_t max_chunk, uint32_t& i) {
+    const unsigned long long fm = __ballot(want);
+    if (!fm) return false;
+    const uint32_t cnt = static_cast<uint32_t>(__popcll(fm));
+    const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(fm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(fm), 0u));
+    const uint32_t avail = q.end - q.next;
+    uint32_t l = q.next + r, c = q.cur;   // entry l of cursor c
+    bool have = want && r < avail;
+    if (avail >= cnt) {
+        q.next += cnt;
+    } else {
+        q.next = q.end;   // the reserve is used up
+        const uint32_t need = cnt - avail;
+        const uint32_t blocks = (n + 255u) >> 8;
+        const uint32_t waves_per_cursor = max(1u, n_waves / kMarchCursors);
+        // one reservation for the lanes still without an entry, from the first cursor that has anything left
+        while (q.tried < kMarchCursors) {
+            const uint32_t len = ((blocks + kMarchCursors - 1u - q.cur) / kMarchCursors) << 8;
+            // (a plain look first: how much is left sizes the chunk, and a cursor that is handed out costs the waves
+            // that come by later no atomic)
+            uint32_t base = __hip_atomic_load(&heads[q.cur][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t left = len > base ? len - base : 0u;
+            const uint32_t chunk = max(need, min(max_chunk, left / (2u * waves_per_cursor)));
+            if (left) {
+                if (__lane_id() == 0) base = atomicAdd(&heads[q.cur][0], chunk);
+                base = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
+            }
+            if (base < len) {
+                const uint32_t end = min(base + chunk, len);
+                if (want && r >= avail) {
+                    l = base + (r - avail);
+                    c = q.cur;
+                    have = l < end;
+                }
+                q.next = min(base + need, end);
+                q.end = end;
+                break;
+            }
+            q.cur = (q.cur + 1u) % kMarchCursors;   // handed out: on to the next cursor
+            ++q.tried;
+            q.next = q.end = 0u;
+        }
+    }
+    i = (((l >> 8) * kMarchCursors + c) << 8) | (l & 255u);
+    return have && i < n;
+}
+
 // The same with eight cursors instead of one: entries are handed out in blocks of 256, block c through
 // cursor c mod 8, and a workgroup starts on cursor blockIdx mod 8 (workgroups go to the XCDs round-robin,
 // so the waves of one XCD share a cursor and work on neighbouring blocks).  A wave whose cursor has run
@@ -1250,23 +1317,32 @@ __device__ __forceinline__ int march_step(March& m, float d2, f3 box, bool short
 // RoughSphereObject, WeirdWallObject); scenes without them run the instantiation that does not carry
 // that code.
 template <bool PLAIN>
-__global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN ? 2 : 3, PLAIN ? 2 : 3))) k_sdf_march(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t round) {
     if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
-    const uint32_t n = pb.counters[bounce].n_sdf;
+    // Work: the marches the previous round's launch handed on (they come first), then this round's rays.
+    const uint32_t n_in = (round > 0u && pb.carry[0]) ? min(pb.counters[round - 1u].n_carry, bp.carry_cap) : 0u;
+    const uint32_t n = n_in + pb.counters[round].n_sdf;
     if (n == 0) return;
-    uint32_t* head = &pb.counters[bounce].sdf_head;
+    const CarryRec* carry_in = pb.carry[(round & 1u) ^ 1u];
+    CarryRec* carry_out = pb.carry[round & 1u];
+    uint32_t (*heads)[32] = pb.counters[round].sdf_heads;
     constexpr int IDLE = 0, SETUP = 1, MARCH = 2;
     int state = IDLE;
-    QueueCursor cursor{0u, 0u, 0u, false};
+    SplitCursor cursor{0u, 0u, blockIdx.x % kMarchCursors, 0u};
     uint32_t slot = 0, k = 0, prim = 0, crater_base = 0, crater_count = 0;
-    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), inv_d = mk3(0, 0, 0), off = mk3(0, 0, 0), best_pos = mk3(0, 0, 0);
+    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), off = mk3(0, 0, 0);
     float inv_len2 = 0.0f, limit = 0.0f;
     unsigned long long best = kMissKey;
     bool improved = false;
+    // 0: a ray of this round's queue.  Otherwise the ray came in as a handed-on march (shading has passed it by and must
+    // see it again): record index + 1, with the top bit set until the march's state has been taken from the record.
+    uint32_t resumed = 0;
     uint32_t plain = 0;   // kind of the lane-evaluated object being marched, 0 for a crater ball
     const f3 ball_box = mk3(1.0f, 1.0f, 1.0f);   // CraterBallObject::localBoundingBox PathTracerDemo.cpp:474-479
     uint32_t c_far = 0, c_near = 0, c_noise = 0;
     __shared__ __attribute__((aligned(16))) float s_coop[4 * kNearLdsFloats];
+    __shared__ uint32_t s_late[4 * 128];
+    PendingQueue late{s_late + (threadIdx.x >> 6) * 128u, 128u, 0u};
     const uint32_t lane = __lane_id();
     float* lds = s_coop + (threadIdx.x >> 6) * kNearLdsFloats;
     const CoopLane cl = make_coop_lane(sc.noise_oct, lane);
@@ -1276,6 +1352,16 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
     m.d = 0.0f;
     m.first = m.sign = false;
     const bool shortcuts = !(bp.flags & kFlagFullMarch);
+    uint32_t dry_rounds = 0;   // rounds since this wave found the queue handed out
+    uint32_t n_late = 0;       // handed-on rays this wave has finished (wave-uniform)
+
+    // The ray in `slot` is done with every SDF primitive: its closest hit goes back to the slot (the position went there
+    // when the hit was found).  A ray that came in as a handed-on march joins this round's live paths, after the
+    // closest-hit stage and ahead of shading.
+    auto ray_done = [&]() {
+        if (improved) pb.hit_key[slot] = best;
+        state = IDLE;
+    };
 
     // When rays are scarce, spread them over the waves instead of letting the first waves take 64 each:
     // a wave serves its lanes' near-field evaluations one after another, so rays per wave is latency.
@@ -1286,16 +1372,23 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
         // shared cursor per chunk, not per lane: the cursor is served one atomic at a time for the whole
         // chip.  Chunks shrink towards the end of the queue so that the last rays spread over the waves.
         uint32_t i = 0;
-        const bool have = cursor_take(cursor, state == IDLE && lane < quota && !cursor_empty(cursor), head, n, n_waves, 256u, i);
+        const bool have = split_take(cursor, state == IDLE && lane < quota && !split_empty(cursor), heads, n, n_waves, 256u, i);
+        bool late_now = false;
+        uint32_t late_slot = 0;
         {
             if (have) {
-                slot = pb.sdf_queue[i];
+                const bool carried = i < n_in;
+                uint4 rec0 = make_uint4(0u, 0u, 0u, 0u);   // slot, primitive, best hit key
+                if (carried) {
+                    rec0 = *reinterpret_cast<const uint4*>(carry_in + i);
+                    slot = rec0.x;
+                } else {
+                    slot = pb.sdf_queue[i - n_in];
+                }
                 o = ld3(pb.ray_o[slot]);
                 d = ld3(pb.ray_d[slot]);
-                inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 inv_len2 = 1.0f / norm_sq(d);
-                best = pb.hit_key[slot];
-                best_pos = ld3(pb.hit_pos[slot]);
+                best = carried ? ((static_cast<unsigned long long>(rec0.w) << 32) | rec0.z) : pb.hit_key[slot];
                 limit = 3.0e38f;
                 if (best != kMissKey) {
                     // recover t from the key to cull boxes behind the analytic hit
@@ -1303,24 +1396,26 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
                     const uint32_t fb = (ob & 0x80000000u) ? (ob ^ 0x80000000u) : ~ob;
                     limit = fmaxf(__uint_as_float(fb), 0.0f) * inv_len2 * 1.00001f + 1e-6f;
                 }
-                improved = false;
-                k = 0;
+                // A handed-on ray's slot holds kCarriedKey, so its key is always written back.  Its march is set up on its
+                // primitive as it was the first time (same ray, same best hit: the same box test and entry point) and
+                // then put where the last launch left it.
+                improved = carried;
+                resumed = carried ? (i + 1u) | 0x80000000u : 0u;
+                k = rec0.y;
                 state = SETUP;
             }
         }
         // (2) set up the march on the next SDF primitive whose box the ray reaches
         while (state == SETUP) {
             if (k == sc.n_sdf) {
-                if (improved) {
-                    pb.hit_key[slot] = best;
-                    pb.hit_pos[slot] = st4(best_pos);
-                }
-                state = IDLE;
+                ray_done();
+                late_now = resumed != 0u;
+                late_slot = slot;
                 break;
             }
             const SdfBox bx = sc.sdf_boxes[k];
             float tn;
-            if (slab(o, inv_d, bx.lo, bx.hi, limit, tn)) {
+            if (slab(o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), bx.lo, bx.hi, limit, tn)) {
                 prim = bx.prim;
                 const PrimRec* pr = sc.prims + prim;
                 const f3 lo = aff_pos(pr->inv, o);
@@ -1334,7 +1429,7 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
                         const unsigned long long key = make_key(t, prim);
                         if (key < best) {
                             best = key;
-                            best_pos = w;
+                            pb.hit_pos[slot] = st4(w);
                             improved = true;
                             limit = fmaxf(t, 0.0f) * inv_len2 * 1.00001f + 1e-6f;
                         }
@@ -1361,8 +1456,29 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
             }
             ++k;
         }
+        if (resumed & 0x80000000u) {
+            resumed &= 0x7fffffffu;
+            if (state == MARCH) {
+                const CarryRec* rec = carry_in + (resumed - 1u);
+                const float4 a = reinterpret_cast<const float4*>(rec)[1], b = reinterpret_cast<const float4*>(rec)[2];
+                const uint4 c = reinterpret_cast<const uint4*>(rec)[3];
+                m.p = mk3(a.x, a.y, a.z);
+                m.d = a.w;
+                m.seen_p = mk3(b.x, b.y, b.z);
+                m.seen_d = b.w;
+                m.iter = c.x & 0xffffu;
+                m.first = (c.x >> 16) & 1u;
+                m.sign = (c.x >> 17) & 1u;
+                m.since = c.y;
+                m.span = c.z;
+            }
+        }
+        if (n_in) {
+            pending_push(late, late_now, late_slot, &pb.counters[round].n_live, pb.queue[round & 1u]);
+            n_late += static_cast<uint32_t>(__popcll(__ballot(late_now)));
+        }
         // leave only when no lane holds a ray and no lane may fetch another one
-        if (__all(state == IDLE) && cursor_empty(cursor)) break;
+        if (__all(state == IDLE) && split_empty(cursor)) break;
         // (3) far-field steps are a handful of flops: take them until a near-field evaluation is due
         int result = 0;
         float s = 0.0f;
@@ -1385,6 +1501,7 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
         wave_near(sc.craters, sc.crater_masks, crater_regs, cl, lds, lane, bp.lane_threshold, wants, m.p, off, s, crater_base, crater_count, d2, c_near, c_noise);
         if (wants) result = march_step(m, d2, ball_box, shortcuts);
         // (5) finished marches fold into the ray's best hit and move on to the next primitive
+        late_now = false;
         if (state == MARCH && result != 0) {
             if (result == 1) {
                 const PrimRec* pr = sc.prims + prim;
@@ -1393,7 +1510,7 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
                 const unsigned long long key = make_key(t, prim);
                 if (key < best) {
                     best = key;
-                    best_pos = w;
+                    pb.hit_pos[slot] = st4(w);
                     improved = true;
                     limit = fmaxf(t, 0.0f) * inv_len2 * 1.00001f + 1e-6f;
                 }
@@ -1403,14 +1520,53 @@ __global__ void __launch_bounds__(256) k_sdf_march(SceneDev sc, BatchParams bp, 
             // after the last SDF primitive the ray is done here and now, so that the lane fetches its next ray at the
             // top of the next round instead of spending that round finding out
             if (k == sc.n_sdf) {
-                if (improved) {
-                    pb.hit_key[slot] = best;
-                    pb.hit_pos[slot] = st4(best_pos);
+                ray_done();
+                late_now = resumed != 0u;
+                late_slot = slot;
+            }
+        }
+        if (n_in) {
+            pending_push(late, late_now, late_slot, &pb.counters[round].n_live, pb.queue[round & 1u]);
+            n_late += static_cast<uint32_t>(__popcll(__ballot(late_now)));
+        }
+        // (6) The queue is handed out and this wave has gone on for a while: what is left are the long marches, a few
+        // lanes of a wave that pays a whole round of evaluations per step while most of the chip has nothing to do.
+        // They go to the next round's launch, which takes them up first and walks them in full waves beside its own
+        // rays.  The path falls one round behind (its bounce number is the round minus PathBuffers::ray_d.w).
+        if (bp.carry_max_lag && split_empty(cursor) && ++dry_rounds > bp.carry_after) {
+            // (the rounds the path has fallen behind so far travel in the w of its direction)
+            const uint32_t lag = state == MARCH ? __float_as_uint(pb.ray_d[slot].w) : 0u;
+            const bool may = state == MARCH && lag < bp.carry_max_lag;
+            const unsigned long long cm = __ballot(may);
+            if (cm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&pb.counters[round].n_carry, static_cast<uint32_t>(__popcll(cm)));
+                base = __shfl(base, 0);
+                const uint32_t at = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(cm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(cm), 0u));
+                if (may && at < bp.carry_cap) {
+                    CarryRec rec;
+                    rec.slot = slot;
+                    rec.k = k;
+                    rec.best_lo = static_cast<uint32_t>(best);
+                    rec.best_hi = static_cast<uint32_t>(best >> 32);
+                    rec.p[0] = m.p.x; rec.p[1] = m.p.y; rec.p[2] = m.p.z;
+                    rec.d = m.d;
+                    rec.seen_p[0] = m.seen_p.x; rec.seen_p[1] = m.seen_p.y; rec.seen_p[2] = m.seen_p.z;
+                    rec.seen_d = m.seen_d;
+                    rec.iter_flags = m.iter | (m.first ? 1u << 16 : 0u) | (m.sign ? 1u << 17 : 0u);
+                    rec.since = m.since;
+                    rec.span = m.span;
+                    rec.pad = 0u;
+                    carry_out[at] = rec;
+                    pb.hit_key[slot] = kCarriedKey;
+                    pb.ray_d[slot] = st4(d, __uint_as_float(lag + 1u));
+                    state = IDLE;
                 }
-                state = IDLE;
             }
         }
     }
+    if (n_in) pending_flush(late, &pb.counters[round].n_live, pb.queue[round & 1u]);
+    if (n_late && lane == 0) atomicAdd(&pb.counters[round].n_late, n_late);
     wave_add_total(&pb.totals->sdf_far_evals, c_far);
     wave_add_total(&pb.totals->sdf_near_evals, c_near);
     wave_add_total(&pb.totals->sdf_noise_calls, c_noise);
@@ -1460,8 +1616,10 @@ __global__ void __launch_bounds__(256) k_sdf_eval(SceneDev sc, uint32_t prim, ui
 // queue through the wave's pending buffer.
 // =============================================================================================
 // Applies one bounce to the path in `slot`; returns whether the path continues.
+// `bounce` is the path's own bounce number: the round of the batch minus `lag`, the rounds the path has fallen behind
+// (k_sdf_march); the lag travels on in the w of the new direction.
 __device__ __forceinline__ bool apply_bounce(const PathBuffers& pb, uint32_t slot, const PrimRegs& pr, f3 world_pos, const Bounce& b,
-                                             uint32_t bounce, uint32_t max_bounces) {
+                                             uint32_t bounce, uint32_t max_bounces, uint32_t lag) {
     const f3 wdir = lin_mul(pr.fwd, b.dir);   // only the direction returns to world space (src/Object.cpp:42)
     const f3 npos = mk3(world_pos.x + 1e-3f * wdir.x, world_pos.y + 1e-3f * wdir.y, world_pos.z + 1e-3f * wdir.z);   // src/Scene.cpp:54
     // a path starts with attenuation 1 and no radiance (src/Scene.cpp:19-20); neither is stored before the first hit
@@ -1484,21 +1642,21 @@ __device__ __forceinline__ bool apply_bounce(const PathBuffers& pb, uint32_t slo
     if (alive) {
         pb.att[slot] = att;
         pb.ray_o[slot] = st4(npos);
-        pb.ray_d[slot] = st4(wdir);
+        pb.ray_d[slot] = st4(wdir, __uint_as_float(lag));
     }
     return alive;
 }
 
-__global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce, uint32_t max_bounces) {
+__global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t round, uint32_t max_bounces) {
     if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
     constexpr uint32_t kCap = 1024;
     __shared__ uint32_t s_pend[2 * 4 * kCap];
     PendingQueue survivors{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u}, sdf_hits{s_pend + (4u + (threadIdx.x >> 6)) * kCap, kCap, 0u};
     __shared__ uint32_t s_host[4 * 128];
     PendingQueue host_hits{s_host + (threadIdx.x >> 6) * 128u, 128u, 0u};
-    const uint32_t n = pb.counters[bounce].n_live;
-    const uint32_t* queue = pb.queue[bounce & 1];
-    uint32_t* next_queue = pb.queue[(bounce + 1) & 1];
+    const uint32_t n = pb.counters[round].n_live;
+    const uint32_t* queue = pb.queue[round & 1];
+    uint32_t* next_queue = pb.queue[(round + 1) & 1];
     const uint32_t stride = gridDim.x * blockDim.x;
     // all lanes of a wave run the same number of iterations so that the wave-wide ballots line up
     const uint32_t rounds = (n + stride - 1) / stride;
@@ -1509,7 +1667,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
         if (i < n) {
             slot = queue[i];
             const unsigned long long key = pb.hit_key[slot];
-            if (key != kMissKey) {
+            if (key != kMissKey && key != kCarriedKey) {   // a path whose march was handed on is shaded in a later round
                 const uint32_t prim = static_cast<uint32_t>(key & 0xffffffffu);
                 PrimRegs pr;
                 load_prim(sc.prims, prim, pr);
@@ -1519,7 +1677,9 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
                     to_sdf = true;
                 } else {
                     const f3 wp = ld3(pb.hit_pos[slot]);
-                    const f3 d = ld3(pb.ray_d[slot]);
+                    const float4 dv = pb.ray_d[slot];
+                    const f3 d = ld3(dv);
+                    const uint32_t lag = __float_as_uint(dv.w), bounce = round - lag;
                     const f3 ld = lin_mul(pr.inv, d);
                     const f3 lp = aff_pos(pr.inv, wp);
                     f3 nrm;
@@ -1539,17 +1699,17 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
                     pixel_of(bp, slot - s_local * bp.n_pix, px, py);
                     Rng rng(bp.seed, py * bp.width + px, bp.first_sample + s_local, 1u + bounce);
                     const Bounce b = deflect(sc.materials[pr.material], ld, nrm, rng);
-                    alive = apply_bounce(pb, slot, pr, wp, b, bounce, max_bounces);
+                    alive = apply_bounce(pb, slot, pr, wp, b, bounce, max_bounces, lag);
                 }
             }
         }
-        pending_push(survivors, alive, slot, &pb.counters[bounce + 1].n_live, next_queue);
-        pending_push(sdf_hits, to_sdf, slot, &pb.counters[bounce].n_sdf_shade, pb.sdf_shade_queue);
-        if (sc.n_host) pending_push(host_hits, to_host, slot, &pb.counters[bounce].n_host_shade, pb.host_queue);
+        pending_push(survivors, alive, slot, &pb.counters[round + 1].n_live, next_queue);
+        pending_push(sdf_hits, to_sdf, slot, &pb.counters[round].n_sdf_shade, pb.sdf_shade_queue);
+        if (sc.n_host) pending_push(host_hits, to_host, slot, &pb.counters[round].n_host_shade, pb.host_queue);
     }
-    pending_flush(survivors, &pb.counters[bounce + 1].n_live, next_queue);
-    pending_flush(sdf_hits, &pb.counters[bounce].n_sdf_shade, pb.sdf_shade_queue);
-    if (sc.n_host) pending_flush(host_hits, &pb.counters[bounce].n_host_shade, pb.host_queue);
+    pending_flush(survivors, &pb.counters[round + 1].n_live, next_queue);
+    pending_flush(sdf_hits, &pb.counters[round].n_sdf_shade, pb.sdf_shade_queue);
+    if (sc.n_host) pending_flush(host_hits, &pb.counters[round].n_host_shade, pb.host_queue);
 }
 
 // =============================================================================================
@@ -1663,10 +1823,10 @@ __global__ void __launch_bounds__(256) k_host_apply(PathBuffers pb, uint32_t n, 
 // the four points of one hit, so a wave shades 16 hits per round; the quad's first lane then deflects
 // the path.  Hits are dealt to waves round-robin so that a short queue spreads over all waves.
 template <bool PLAIN>
-__device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, uint32_t max_bounces) {
+__device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t round, uint32_t max_bounces) {
     if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
-    const uint32_t n = pb.counters[bounce].n_sdf_shade;
-    uint32_t* next_queue = pb.queue[(bounce + 1) & 1];
+    const uint32_t n = pb.counters[round].n_sdf_shade;
+    uint32_t* next_queue = pb.queue[(round + 1) & 1];
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t per_round = n_waves * 16u;
     const uint32_t rounds = (n + per_round - 1) / per_round;
@@ -1689,6 +1849,7 @@ __device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchPa
         PrimRegs pr;
         f3 wp = mk3(0, 0, 0), ld = mk3(0, 0, 0), p = mk3(0, 0, 0), off = mk3(0, 0, 0), local_hit = mk3(0, 0, 0);
         float s = 0.0f;
+        uint32_t lag = 0;   // rounds the path has fallen behind: its bounce number is round - lag
         bool fractal = false;
         uint32_t plain = 0;   // kind of a lane-evaluated object, else 0
         if (valid) {
@@ -1696,7 +1857,9 @@ __device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchPa
             const uint32_t prim = static_cast<uint32_t>(pb.hit_key[slot] & 0xffffffffu);
             load_prim(sc.prims, prim, pr);
             wp = ld3(pb.hit_pos[slot]);
-            const f3 d = ld3(pb.ray_d[slot]);
+            const float4 dv = pb.ray_d[slot];
+            const f3 d = ld3(dv);
+            lag = __float_as_uint(dv.w);
             ld = lin_mul(pr.inv, d);
             const f3 lp = aff_pos(pr.inv, wp);
             fractal = pr.kind == 4u;
@@ -1747,6 +1910,7 @@ __device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchPa
             const uint32_t s_local = slot / bp.n_pix;
             uint32_t px, py;
             pixel_of(bp, slot - s_local * bp.n_pix, px, py);
+            const uint32_t bounce = round - lag;
             Rng rng(bp.seed, py * bp.width + px, bp.first_sample + s_local, 1u + bounce);
             Bounce b;
             if (PLAIN && plain) {   // the procedural materials of PathTracerDemo.cpp:184-199, 248-259, 330-341
@@ -1772,11 +1936,11 @@ __device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchPa
             } else {
                 b = deflect(sc.materials[pr.material], ld, nrm, rng);
             }
-            alive = apply_bounce(pb, slot, pr, wp, b, bounce, max_bounces);
+            alive = apply_bounce(pb, slot, pr, wp, b, bounce, max_bounces, lag);
         }
-        pending_push(survivors, alive, slot, &pb.counters[bounce + 1].n_live, next_queue);
+        pending_push(survivors, alive, slot, &pb.counters[round + 1].n_live, next_queue);
     }
-    pending_flush(survivors, &pb.counters[bounce + 1].n_live, next_queue);
+    pending_flush(survivors, &pb.counters[round + 1].n_live, next_queue);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.totals->sdf_shades, static_cast<unsigned long long>(n));
     if (rounds) {
         wave_add_total(&pb.totals->shade_near_evals, c_evals);
@@ -1786,18 +1950,25 @@ __device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchPa
 
 // Three waves per SIMD for the crater-ball instantiation (the register allocator would otherwise take one
 // register too many for that); the instantiation with the lane-evaluated kinds needs more and runs two.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_shade_sdf(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_shade_sdf(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t round,
                                                                                            uint32_t max_bounces) {
-    shade_sdf_body<false>(sc, bp, pb, bounce, max_bounces);
+    shade_sdf_body<false>(sc, bp, pb, round, max_bounces);
 }
-__global__ void __launch_bounds__(256) k_shade_sdf_plain(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce, uint32_t max_bounces) {
-    shade_sdf_body<true>(sc, bp, pb, bounce, max_bounces);
+__global__ void __launch_bounds__(256) k_shade_sdf_plain(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t round, uint32_t max_bounces) {
+    shade_sdf_body<true>(sc, bp, pb, round, max_bounces);
 }
 
-__global__ void k_finish_batch(PathBuffers pb, uint32_t bounces, uint32_t n_slots) {
+__global__ void k_finish_batch(PathBuffers pb, uint32_t rounds, uint32_t n_slots, uint32_t carry_cap) {
     unsigned long long rays = n_slots;   // every path casts its primary ray; later casts are the queue lengths
-    for (uint32_t b = 1; b < bounces; ++b) rays += pb.counters[b].n_live;
-    pb.totals->rays += rays;
+    for (uint32_t r = 1; r < rounds; ++r) rays += pb.counters[r].n_live;
+    // a ray whose march was handed on stands in two rounds' queues: the one it was cast in and the one it was finished in
+    unsigned long long carried = 0, late = 0;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        carried += min(pb.counters[r].n_carry, carry_cap);
+        late += pb.counters[r].n_late;
+    }
+    pb.totals->rays += rays - late;
+    pb.totals->marches_carried += carried;
 }
 
 __global__ void k_latch_cancel(PathBuffers pb) { *pb.cancel_latch = pb.cancel ? *pb.cancel : 0u; }
@@ -2082,8 +2253,8 @@ void launch_host_apply(hipStream_t st, const PathBuffers& pb, uint32_t n, const 
     hipLaunchKernelGGL(k_host_apply, dim3(grid_for(n, 256u * 8u)), dim3(256), 0, st, pb, n, bounce9, bounce, max_bounces);
 }
 
-void launch_finish_batch(hipStream_t st, const PathBuffers& pb, uint32_t bounces, uint32_t n_slots) {
-    hipLaunchKernelGGL(k_finish_batch, dim3(1), dim3(1), 0, st, pb, bounces, n_slots);
+void launch_finish_batch(hipStream_t st, const PathBuffers& pb, uint32_t rounds, uint32_t n_slots, uint32_t carry_cap) {
+    hipLaunchKernelGGL(k_finish_batch, dim3(1), dim3(1), 0, st, pb, rounds, n_slots, carry_cap);
 }
 
 void launch_latch_cancel(hipStream_t st, const PathBuffers& pb) { hipLaunchKernelGGL(k_latch_cancel, dim3(1), dim3(1), 0, st, pb); }

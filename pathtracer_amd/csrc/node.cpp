@@ -26,6 +26,7 @@ struct Rccl {
     void* lib = nullptr;
     int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
     int (*CommDestroy)(void* comm) = nullptr;
+    int (*CommAbort)(void* comm) = nullptr;   // optional: drops what is queued on a communicator whose collective cannot complete
     int (*AllReduce)(const void* send, void* recv, size_t count, int datatype, int op, void* comm, hipStream_t stream) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
@@ -36,6 +37,7 @@ struct Rccl {
         if (!lib) return false;
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));
         AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
@@ -63,6 +65,7 @@ struct mipt_node {
     float* mapped = nullptr;           // on the first device: the tone-mapped frame
     size_t mapped_floats = 0;
     bool simulated = false;
+    bool broken = false;               // a collective failed half-way: the communicators cannot be used again
     Rccl rccl;
     std::mutex mutex;
 };
@@ -133,7 +136,7 @@ int mipt_init_all(int n_devices, const int* devices, uint32_t flags, mipt_node**
 void mipt_node_shutdown(mipt_node* node) {
     if (!node) return;
     for (void* c : node->comm)
-        if (c) (void)node->rccl.CommDestroy(c);
+        if (c) (void)((node->broken && node->rccl.CommAbort) ? node->rccl.CommAbort(c) : node->rccl.CommDestroy(c));
     for (size_t i = 0; i < node->ctx.size(); ++i) {
         (void)hipSetDevice(node->devices[i]);
         if (node->sum[i]) (void)hipFree(node->sum[i]);
@@ -199,6 +202,7 @@ int mipt_node_render(mipt_node* node, const mipt_node_scene* ns, const mipt_came
     if (!node || !ns || !cam || !st || !out_rgb || tonemap < -1 || tonemap > 1 || ns->scene.size() != node->ctx.size()) return MIPT_ERR_ARGUMENT;
     if (st->width < 2 || st->height < 2 || st->spp == 0) return MIPT_ERR_ARGUMENT;
     std::lock_guard<std::mutex> lock(node->mutex);
+    if (node->broken) return MIPT_ERR_HIP;
     const size_t n = node->ctx.size();
     const size_t floats = static_cast<size_t>(st->width) * st->height * 3;
     // per-shard sum buffers (and the mapped frame on the first device), grown on demand
@@ -253,11 +257,17 @@ int mipt_node_render(mipt_node* node, const mipt_node_scene* ns, const mipt_came
     for (size_t i = 0; i < n; ++i) samples_in += sst[i].samples_done;
     if (!node->simulated) {
         if (node->rccl.GroupStart() != 0) return MIPT_ERR_HIP;
-        for (size_t i = 0; i < n; ++i) {
-            if (hipSetDevice(node->devices[i]) != hipSuccess) return MIPT_ERR_HIP;
-            if (node->rccl.AllReduce(node->sum[i], node->sum[i], floats, kNcclFloat32, kNcclSum, node->comm[i], node->stream[i]) != 0) return MIPT_ERR_HIP;
+        // The group is closed on every way out.  An all-reduce that only some shards joined cannot complete, so after
+        // a failure inside the bracket the node refuses further frames (mipt_node_shutdown aborts what is queued).
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; ++i)
+            ok = hipSetDevice(node->devices[i]) == hipSuccess &&
+                 node->rccl.AllReduce(node->sum[i], node->sum[i], floats, kNcclFloat32, kNcclSum, node->comm[i], node->stream[i]) == 0;
+        if (node->rccl.GroupEnd() != 0) ok = false;
+        if (!ok) {
+            node->broken = true;
+            return MIPT_ERR_HIP;
         }
-        if (node->rccl.GroupEnd() != 0) return MIPT_ERR_HIP;
         for (size_t i = 0; i < n; ++i) {
             if (hipSetDevice(node->devices[i]) != hipSuccess || hipStreamSynchronize(node->stream[i]) != hipSuccess) return MIPT_ERR_HIP;
         }
@@ -290,6 +300,12 @@ int mipt_node_render(mipt_node* node, const mipt_node_scene* ns, const mipt_came
             stats->samples_done += sst[i].samples_done;
             stats->host_rays += sst[i].host_rays;
             stats->host_shades += sst[i].host_shades;
+            stats->node_visits += sst[i].node_visits;   // counting build (mipt_set_counting on the shards' contexts)
+            stats->prim_tests += sst[i].prim_tests;
+            stats->trav_rounds += sst[i].trav_rounds;
+            stats->trav_leaf_steps += sst[i].trav_leaf_steps;
+            stats->trav_restarts += sst[i].trav_restarts;
+            stats->marches_carried += sst[i].marches_carried;
             stats->ms_device = std::max(stats->ms_device, sst[i].ms_device);   // the shards run side by side
         }
     }

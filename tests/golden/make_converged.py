@@ -27,7 +27,14 @@ CASES = {
     "roughbox": (lambda a, n: G.roughbox_scene(a, n), lambda a: G.roughbox_camera(a), 24, 24, 5, 1024),
     "roughsphere": (lambda a, n: G.roughsphere_scene(a, n), lambda a: G.sdf_camera(a, -8.0, 14.0), 24, 24, 5, 1024),
     "weirdwall": (lambda a, n: G.weirdwall_scene(a, n), lambda a: G.sdf_camera(a, -14.0, 20.0, -0.5), 24, 24, 5, 768),
+    # the headline frame's own view (PathTracerDemo.cpp:897-903 with the aspect the demo sets on resize, :991-993) at a
+    # quarter of 1920 x 1080
+    "demo_view": (lambda a, n: S.demo_scene(a, n), lambda a: S.demo_camera(a, 16.0 / 9.0), 480, 270, 8, 4096),
 }
+
+# Cases whose images are means over that many independent renders of spp / parts samples each (one worker thread per
+# render keeps every part reproducible; the parts of seed s use the seeds 10 s + part).
+PARTS = {"demo_view": 4}
 
 
 EXTRA_SEEDS = (11, 12, 13, 14, 15, 16, 17)     # with a and b: nine images behind every <name>_m
@@ -35,11 +42,13 @@ NOISY = ("roughbox", "roughsphere", "weirdwall")  # two seeds alone leave ~1 % o
 
 
 def _render(job):
-    name, seed = job
+    name, seed, part = job
     ref = orc.Reference()
     noise = ref.init_noise(G.NOISE_SEED)
     mk_scene, mk_cam, w, h, bounces, spp = CASES[name]
-    return name, seed, ref.scene(mk_scene(ref, noise)).render(mk_cam(ref), w, h, bounces, spp, seed=seed, threads=1)
+    parts = PARTS.get(name, 1)
+    run_seed = seed if parts == 1 else 10 * seed + part
+    return name, seed, ref.scene(mk_scene(ref, noise)).render(mk_cam(ref), w, h, bounces, spp // parts, seed=run_seed, threads=1)
 
 
 def main():
@@ -52,16 +61,23 @@ def main():
         old = np.load(path, allow_pickle=False)
         assert np.array_equal(old["noise12"], noise)
         blob.update({k: old[k] for k in old.files})
-    jobs = [(name, seed) for name in CASES if name + "_cfg" not in blob for seed in (1001, 2002)]
-    jobs += [(name, seed) for name in NOISY if name + "_m" not in blob for seed in EXTRA_SEEDS]
+    jobs = [(name, seed, part) for name in CASES if name + "_cfg" not in blob for seed in (1001, 2002)
+            for part in range(PARTS.get(name, 1))]
+    jobs += [(name, seed, 0) for name in NOISY if name + "_m" not in blob for seed in EXTRA_SEEDS]
     extra = {name: [] for name in NOISY}
+    sums = {}
     with mp.get_context("spawn").Pool(min(8, os.cpu_count() or 1)) as pool:
         for name, seed, img in pool.imap_unordered(_render, jobs):
             print(name, seed, "mean", float(img.mean()), flush=True)
             if seed in EXTRA_SEEDS:
                 extra[name].append((seed, img))
             else:
-                blob[f"{name}_{'a' if seed == 1001 else 'b'}"] = img
+                acc = sums.setdefault((name, seed), [np.zeros(img.shape, np.float64), 0])
+                acc[0] += img
+                acc[1] += 1
+    for (name, seed), (total, count) in sums.items():
+        assert count == PARTS.get(name, 1)
+        blob[f"{name}_{'a' if seed == 1001 else 'b'}"] = (total / count).astype(np.float32)
     for name, (_, _, w, h, bounces, spp) in CASES.items():
         blob[f"{name}_cfg"] = np.array([w, h, bounces, spp], np.int64)
         if extra.get(name):
