@@ -119,6 +119,11 @@ struct SceneDev {
     uint32_t n_host;
 };
 
+#ifndef MIPT_MARCH_CURSORS
+#define MIPT_MARCH_CURSORS 16
+#endif
+constexpr uint32_t kMarchCursors = MIPT_MARCH_CURSORS;
+
 // Per-bounce queue counters of one sample batch, zeroed once per batch.
 struct BounceCounters {
     uint32_t n_live;        // entries in the path queue feeding this bounce (bounce > 0)
@@ -131,8 +136,8 @@ struct BounceCounters {
     uint32_t n_carry;       // SDF marches this round's launch left unfinished for the next round's (may exceed the buffer: readers clamp)
     uint32_t n_late;        // rays of earlier rounds whose handed-on march this round's launch finished (they joined n_live)
     uint32_t pad2[12];
-    // work-fetch cursors of the SDF march (kMarchCursors), each on a cache line of its own: atomics on one line are served one at a time
-    uint32_t sdf_heads[16][32];
+    // work-fetch cursors of the SDF march, each on a cache line of its own: atomics on one line are served one at a time
+    uint32_t sdf_heads[kMarchCursors][32];
 };
 
 // An SDF march that its launch handed on to the next round's launch instead of finishing it (k_sdf_march): everything

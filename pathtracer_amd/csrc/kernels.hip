@@ -871,6 +871,27 @@ __device__ __forceinline__ void pending_push(PendingQueue& q, bool pred, uint32_
     q.count += static_cast<uint32_t>(__popcll(m));
 }
 
+// The last flush of a workgroup's four waves with one atomic instead of four: every wave of the chip ends its kernel
+// with a flush, all at about the same time and all on one counter, which serves them one after another.  Every
+// thread of the workgroup calls, once, after its wave's last push (`s_meet`: 8 words of LDS).
+__device__ __forceinline__ void pending_flush_block(PendingQueue& q, uint32_t* counter, uint32_t* queue, uint32_t* s_meet) {
+    const uint32_t wave = threadIdx.x >> 6, lane = __lane_id();
+    if (lane == 0) s_meet[wave] = q.count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t c0 = s_meet[0], c1 = s_meet[1], c2 = s_meet[2], c3 = s_meet[3], total = c0 + c1 + c2 + c3;
+        const uint32_t base = total ? atomicAdd(counter, total) : 0u;
+        s_meet[4] = base;
+        s_meet[5] = base + c0;
+        s_meet[6] = base + c0 + c1;
+        s_meet[7] = base + c0 + c1 + c2;
+    }
+    __syncthreads();
+    const uint32_t base = s_meet[4u + wave];
+    for (uint32_t i = lane; i < q.count; i += 64u) queue[base + i] = q.buf[i];
+    q.count = 0;
+}
+
 // A wave's share of a work queue: entries are reserved a chunk at a time, one atomic on the shared
 // cursor per chunk (the cursor is served one atomic at a time for the whole chip); chunks shrink towards
 // the end of the queue so that the last entries spread over the waves.
@@ -917,10 +938,6 @@ __device__ __forceinline__ bool cursor_take(QueueCursor& q, bool want, uint32_t*
 // starts with some of the queue's first entries, and a full chunk is still 256 neighbours of the queue: rays of
 // neighbouring pixels, which walk the same craters); a wave starts on the cursor of its workgroup and moves on when
 // that one is handed out.  Which wave processes which entry never matters for the result.
-#ifndef MIPT_MARCH_CURSORS
-#define MIPT_MARCH_CURSORS 16
-#endif
-constexpr uint32_t kMarchCursors = MIPT_MARCH_CURSORS;
 struct SplitCursor {
     uint32_t next, end;         // wave-uniform: reserved range, in the current cursor's own numbering
     uint32_t cur, tried;        // cursor in use, cursors found handed out
@@ -1041,21 +1058,19 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
         for (int k = 0; k < cull.n; ++k)
             visible = visible || (static_cast<int>(x) >= cull.r[k][0] && static_cast<int>(y) >= cull.r[k][1] && static_cast<int>(x) <= cull.r[k][2] &&
                                   static_cast<int>(y) <= cull.r[k][3]);
-    if (!__ballot(visible)) {
+    const bool wave_sees = __ballot(visible) != 0ull;
+    if (!wave_sees && __ballot(in_image)) {
         // nothing for this wave to trace: its words of the live-path bitmap are all that is owed
-        if (__ballot(in_image)) {
-            const uint32_t word = (blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) >> 6;
-            for (uint32_t s = blockIdx.y + (threadIdx.x & 63u) * gridDim.y; s < samples; s += 64u * gridDim.y)
-                pb.live_bits[static_cast<size_t>(s) * words_per_sample + word] = 0ull;
-        }
-        return;
+        const uint32_t word = (blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) >> 6;
+        for (uint32_t s = blockIdx.y + (threadIdx.x & 63u) * gridDim.y; s < samples; s += 64u * gridDim.y)
+            pb.live_bits[static_cast<size_t>(s) * words_per_sample + word] = 0ull;
     }
     uint32_t s_next = visible ? blockIdx.y : samples;    // this lane's next sample
     uint32_t s_cur = blockIdx.y - gridDim.y;             // wave-uniform (wraps; advanced before use)
     Trav t;
     t.busy = false;
     TravCounts counts{0u, 0u};
-    for (;;) {
+    while (wave_sees) {
         // refill: idle lanes start their next sample
         if (!t.busy && s_next < samples) {
             f3 o, d;
@@ -1094,8 +1109,10 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
         pending_push(to_sdf, wants_sdf, t.slot, &pb.counters[0].n_sdf, pb.sdf_queue);
         n_sdf_rays += wants_sdf ? 1u : 0u;
     }
-    pending_flush(live, &pb.counters[0].n_live, pb.queue[0]);
-    pending_flush(to_sdf, &pb.counters[0].n_sdf, pb.sdf_queue);
+    __syncthreads();   // every wave is done with its traversal stack: its first words serve the flush
+    uint32_t* s_meet = reinterpret_cast<uint32_t*>(s_stack);
+    pending_flush_block(live, &pb.counters[0].n_live, pb.queue[0], s_meet);
+    pending_flush_block(to_sdf, &pb.counters[0].n_sdf, pb.sdf_queue, s_meet);
     wave_add_total(&pb.totals->sdf_rays, n_sdf_rays);
     wave_add_total(&pb.totals->primary_traced, visible ? (samples - blockIdx.y + gridDim.y - 1u) / gridDim.y : 0u);
     if (COUNT) {
@@ -1158,7 +1175,8 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
         pending_push(to_sdf, wants_sdf, t.slot, &pb.counters[bounce].n_sdf, pb.sdf_queue);
         n_sdf_rays += wants_sdf ? 1u : 0u;
     }
-    pending_flush(to_sdf, &pb.counters[bounce].n_sdf, pb.sdf_queue);
+    __syncthreads();   // every wave is done with its traversal stack: its first words serve the flush
+    pending_flush_block(to_sdf, &pb.counters[bounce].n_sdf, pb.sdf_queue, reinterpret_cast<uint32_t*>(s_stack));
     wave_add_total(&pb.totals->sdf_rays, n_sdf_rays);
     if (COUNT) {
         wave_add_total(&pb.totals->node_visits, counts.nodes);
@@ -1222,7 +1240,8 @@ __global__ void __launch_bounds__(256) k_extend_pair(SceneDev sc, BatchParams bp
         const uint32_t n_busy = static_cast<uint32_t>(__popcll(__ballot(pair_busy(r0))) + __popcll(__ballot(pair_busy(r1))));
         trav_run_pair<S, COUNT, DIST>(sc, pb, r0, r1, col, rows, xcd_cursor_empty(cursor) ? 0u : (bp.trav_keep_pair * n_busy) / 128u, counts, bp.trav_quorum_pair);
     }
-    pending_flush(to_sdf, &pb.counters[bounce].n_sdf, pb.sdf_queue);
+    __syncthreads();   // every wave is done with its traversal stack: its first words serve the flush
+    pending_flush_block(to_sdf, &pb.counters[bounce].n_sdf, pb.sdf_queue, reinterpret_cast<uint32_t*>(s_stack));
     wave_add_total(&pb.totals->sdf_rays, n_sdf_rays);
     if (COUNT) {
         wave_add_total(&pb.totals->node_visits, counts.nodes);
@@ -1329,9 +1348,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN 
     constexpr int IDLE = 0, SETUP = 1, MARCH = 2;
     int state = IDLE;
     SplitCursor cursor{0u, 0u, blockIdx.x % kMarchCursors, 0u};
-    uint32_t slot = 0, k = 0, prim = 0, crater_base = 0, crater_count = 0;
-    f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), off = mk3(0, 0, 0);
-    float inv_len2 = 0.0f, limit = 0.0f;
+    // Per lane, between rounds: the ray's slot, the SDF primitive it is on, its best hit so far and the march.  The ray
+    // itself is read from the slot where it is needed (set-up, the end of a march): registers are what limits this
+    // kernel to three waves per SIMD.
+    uint32_t slot = 0, k = 0, crater_base = 0, crater_count = 0;
+    f3 off = mk3(0, 0, 0);
     unsigned long long best = kMissKey;
     bool improved = false;
     // 0: a ray of this round's queue.  Otherwise the ray came in as a handed-on march (shading has passed it by and must
@@ -1385,17 +1406,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN 
                 } else {
                     slot = pb.sdf_queue[i - n_in];
                 }
-                o = ld3(pb.ray_o[slot]);
-                d = ld3(pb.ray_d[slot]);
-                inv_len2 = 1.0f / norm_sq(d);
                 best = carried ? ((static_cast<unsigned long long>(rec0.w) << 32) | rec0.z) : pb.hit_key[slot];
-                limit = 3.0e38f;
-                if (best != kMissKey) {
-                    // recover t from the key to cull boxes behind the analytic hit
-                    const uint32_t ob = static_cast<uint32_t>(best >> 32);
-                    const uint32_t fb = (ob & 0x80000000u) ? (ob ^ 0x80000000u) : ~ob;
-                    limit = fmaxf(__uint_as_float(fb), 0.0f) * inv_len2 * 1.00001f + 1e-6f;
-                }
                 // A handed-on ray's slot holds kCarriedKey, so its key is always written back.  Its march is set up on its
                 // primitive as it was the first time (same ray, same best hit: the same box test and entry point) and
                 // then put where the last launch left it.
@@ -1406,6 +1417,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN 
             }
         }
         // (2) set up the march on the next SDF primitive whose box the ray reaches
+        f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
+        float inv_len2 = 0.0f, limit = 3.0e38f;
+        if (state == SETUP) {
+            o = ld3(pb.ray_o[slot]);
+            d = ld3(pb.ray_d[slot]);
+            inv_len2 = 1.0f / norm_sq(d);
+            if (best != kMissKey) {
+                // recover t from the key to cull boxes behind the best hit
+                const uint32_t ob = static_cast<uint32_t>(best >> 32);
+                const uint32_t fb = (ob & 0x80000000u) ? (ob ^ 0x80000000u) : ~ob;
+                limit = fmaxf(__uint_as_float(fb), 0.0f) * inv_len2 * 1.00001f + 1e-6f;
+            }
+        }
         while (state == SETUP) {
             if (k == sc.n_sdf) {
                 ray_done();
@@ -1416,7 +1440,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN 
             const SdfBox bx = sc.sdf_boxes[k];
             float tn;
             if (slab(o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), bx.lo, bx.hi, limit, tn)) {
-                prim = bx.prim;
+                const uint32_t prim = bx.prim;
                 const PrimRec* pr = sc.prims + prim;
                 const f3 lo = aff_pos(pr->inv, o);
                 const f3 ld = lin_mul(pr->inv, d);
@@ -1504,15 +1528,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN 
         late_now = false;
         if (state == MARCH && result != 0) {
             if (result == 1) {
+                const uint32_t prim = sc.sdf_boxes[k].prim;
                 const PrimRec* pr = sc.prims + prim;
                 const f3 w = aff_pos(pr->fwd, m.p);
-                const float t = dot(w - o, d);
+                const float t = dot(w - ld3(pb.ray_o[slot]), ld3(pb.ray_d[slot]));
                 const unsigned long long key = make_key(t, prim);
                 if (key < best) {
                     best = key;
                     pb.hit_pos[slot] = st4(w);
                     improved = true;
-                    limit = fmaxf(t, 0.0f) * inv_len2 * 1.00001f + 1e-6f;
                 }
             }
             ++k;
@@ -1535,7 +1559,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN 
         // rays.  The path falls one round behind (its bounce number is the round minus PathBuffers::ray_d.w).
         if (bp.carry_max_lag && split_empty(cursor) && ++dry_rounds > bp.carry_after) {
             // (the rounds the path has fallen behind so far travel in the w of its direction)
-            const uint32_t lag = state == MARCH ? __float_as_uint(pb.ray_d[slot].w) : 0u;
+            float4 dv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (state == MARCH) dv = pb.ray_d[slot];
+            const uint32_t lag = __float_as_uint(dv.w);
             const bool may = state == MARCH && lag < bp.carry_max_lag;
             const unsigned long long cm = __ballot(may);
             if (cm) {
@@ -1559,7 +1585,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN 
                     rec.pad = 0u;
                     carry_out[at] = rec;
                     pb.hit_key[slot] = kCarriedKey;
-                    pb.ray_d[slot] = st4(d, __uint_as_float(lag + 1u));
+                    dv.w = __uint_as_float(lag + 1u);
+                    pb.ray_d[slot] = dv;
                     state = IDLE;
                 }
             }
@@ -1707,8 +1734,9 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev sc, BatchParams bp, Path
         pending_push(sdf_hits, to_sdf, slot, &pb.counters[round].n_sdf_shade, pb.sdf_shade_queue);
         if (sc.n_host) pending_push(host_hits, to_host, slot, &pb.counters[round].n_host_shade, pb.host_queue);
     }
-    pending_flush(survivors, &pb.counters[round + 1].n_live, next_queue);
-    pending_flush(sdf_hits, &pb.counters[round].n_sdf_shade, pb.sdf_shade_queue);
+    __shared__ uint32_t s_meet[8];
+    pending_flush_block(survivors, &pb.counters[round + 1].n_live, next_queue, s_meet);
+    pending_flush_block(sdf_hits, &pb.counters[round].n_sdf_shade, pb.sdf_shade_queue, s_meet);
     if (sc.n_host) pending_flush(host_hits, &pb.counters[round].n_host_shade, pb.host_queue);
 }
 
@@ -1940,7 +1968,8 @@ __device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchPa
         }
         pending_push(survivors, alive, slot, &pb.counters[round + 1].n_live, next_queue);
     }
-    pending_flush(survivors, &pb.counters[round + 1].n_live, next_queue);
+    __shared__ uint32_t s_meet[8];
+    pending_flush_block(survivors, &pb.counters[round + 1].n_live, next_queue, s_meet);
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.totals->sdf_shades, static_cast<unsigned long long>(n));
     if (rounds) {
         wave_add_total(&pb.totals->shade_near_evals, c_evals);
