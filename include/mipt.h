@@ -258,11 +258,18 @@ int  mipt_primary_hits(mipt_ctx*, const mipt_scene*, const mipt_camera*, uint32_
 int  mipt_trace_rays(mipt_ctx*, const mipt_scene*, uint32_t n, const float* ray_pos3, const float* ray_dir3,
                      uint32_t bounces, uint64_t seed, float* out_rgb, int32_t* out_first_prim, float* out_first_t);
 
-/* The signed distance of SDF primitive `prim` (kinds MIPT_CRATERBALL and up) at n points of the object's LOCAL frame,
+/* The signed distance of SDF primitive `prim` (kinds MIPT_CRATERBALL to MIPT_WEIRDWALL) at n points of the object's LOCAL frame,
  * evaluated by the device code the march uses: CraterBallObject::signedDistance (PathTracerDemo.cpp:361-466),
  * FractalObject::signedDistance (src/Object.cpp:198-252), RoughBoxObject (:237-246), RoughSphereObject (:165-182),
  * WeirdWallObject (:281-328).  pos3 = n x 3 floats, out = n floats (host). */
 int  mipt_sdf_eval(mipt_ctx*, const mipt_scene*, uint32_t prim, uint32_t n, const float* pos3, float* out);
+/* The material a hit at each of n LOCAL points of SDF primitive `prim` is shaded with, by the device code shading uses:
+ * what the object's deflectLocalRay makes of its material there -- RoughSphereObject (PathTracerDemo.cpp:184-199),
+ * RoughBoxObject (:248-259), WeirdWallObject (:330-341); the primitive's own material row for CraterBallObject (:468-472)
+ * and FractalObject (src/Object.cpp:177-189).  out9 = n x 9 floats {reflected absorption r g b, emitted luminance r g b,
+ * diffuse, specular, sharpness} (host).  Both probes refuse primitives that are not SDF objects with a device form
+ * (MIPT_ERR_ARGUMENT), MIPT_HOST_OBJECT included. */
+int  mipt_sdf_material_eval(mipt_ctx*, const mipt_scene*, uint32_t prim, uint32_t n, const float* pos3, float* out9);
 
 /* ---- one process, several GPUs -------------------------------------------------------------------------
  * Renderer::render (src/Renderer.cpp:139-172) across the GPUs of a node, where the reference spreads 8-pixel tasks
@@ -285,6 +292,10 @@ int  mipt_node_size(const mipt_node*);
 mipt_ctx* mipt_node_ctx(mipt_node*, int shard);
 int  mipt_node_cancel(mipt_node*);                                   /* Renderer::cancelRender for every shard */
 int  mipt_node_scene_upload(mipt_node*, const mipt_scene_desc*, mipt_node_scene** out);   /* Scene::updateGeometry on every device */
+/* The same for scenes that hold MIPT_HOST_OBJECT primitives (mipt_scene_upload_host on every device): every shard hands the
+ * rays that reach such an object to the callbacks from host threads of its own, so the callbacks run from all shards
+ * at once (they must be re-entrant anyway, include/Object.hpp:45-52).  mipt_stats::host_rays / host_shades are summed. */
+int  mipt_node_scene_upload_host(mipt_node*, const mipt_scene_desc*, const mipt_host_callbacks*, mipt_node_scene** out);
 void mipt_node_scene_free(mipt_node*, mipt_node_scene*);
 /* tonemap: -1 none, 0 Reinhard, 1 filmic (src/ToneMapper.cpp), applied on the GPU after the all-reduce */
 int  mipt_node_render(mipt_node*, const mipt_node_scene*, const mipt_camera*, const mipt_settings*, int tonemap, float* out_rgb,

@@ -301,6 +301,11 @@ struct DevicePrimitive {
     const BasicMaterial* material = nullptr;
     const char* type_name = "";
     const float* noise = nullptr;   // 12 floats: set by SDF kinds that carry their own noise transform
+    // Set by SDFObjectCRTP: the object's own signedDistance and local bounding box.  A device twin is only trusted after
+    // it has returned the object's own values at probe points (a class recognised by name may have been edited).
+    float (*probe_sdf)(const void* object, const float local_pos[3]) = nullptr;
+    const void* probe_object = nullptr;
+    float probe_box[6] = {};    // localBoundingBox(): centre, half size
 };
 }   // namespace mipt_host
 
@@ -405,6 +410,13 @@ public:
         out.type_name = typeid(Derived).name();
         out.material = &material;
         out.kind = -1;
+        out.probe_object = self;
+        out.probe_sdf = [](const void* object, const float p[3]) noexcept -> float {
+            return static_cast<const Derived*>(object)->signedDistance(Pos(p[0], p[1], p[2]));
+        };
+        const AxisAlignedBox bb = self->localBoundingBox();
+        const float box[6] = {bb.center.x, bb.center.y, bb.center.z, bb.halfSize.x, bb.halfSize.y, bb.halfSize.z};
+        for (int k = 0; k < 6; ++k) out.probe_box[k] = box[k];
         if (mipt_host::DeviceSdf<Derived>::describe(*self, out)) return;
         mipt_host::describeKnownDemoSdf(typeid(Derived).name(), sizeof(Derived), sizeof(SDFObjectCRTP<Derived>), self, out);
     }

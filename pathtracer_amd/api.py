@@ -64,6 +64,24 @@ class HostAlgebra:
 UPLOAD_DEVICE_BVH = 1
 
 
+def host_callbacks(host_hit, host_deflect):
+    """mipt_host_callbacks around two Python functions: host_hit(prim, pos3, dir3) -> hit position or None,
+    host_deflect(prim, pos3, dir3) -> 9 floats (emitted, attenuation, world direction)."""
+    def _hit(_user, prim, pos, dirs, out):
+        r = host_hit(int(prim), np.ctypeslib.as_array(pos, (3,)).copy(), np.ctypeslib.as_array(dirs, (3,)).copy())
+        if r is None:
+            return 0
+        out[0], out[1], out[2] = float(r[0]), float(r[1]), float(r[2])
+        return 1
+
+    def _deflect(_user, prim, pos, dirs, out):
+        r = host_deflect(int(prim), np.ctypeslib.as_array(pos, (3,)).copy(), np.ctypeslib.as_array(dirs, (3,)).copy())
+        for k in range(9):
+            out[k] = float(r[k])
+
+    return capi.HostCallbacks(capi.HIT_FN(_hit), capi.DEFLECT_FN(_deflect), None)
+
+
 class DeviceScene:
     def __init__(self, ctx, flat, flags=None, host_hit=None, host_deflect=None):
         """host_hit(prim, pos3, dir3) -> hit position (3 floats) or None, host_deflect(prim, pos3, dir3) -> 9 floats
@@ -76,19 +94,7 @@ class DeviceScene:
                            mat.ctypes.data_as(capi._u32p), mats.shape[0], fp(mats), fp(noise))
         h = C.c_void_p()
         if host_hit is not None:
-            def _hit(_user, prim, pos, dirs, out):
-                r = host_hit(int(prim), np.ctypeslib.as_array(pos, (3,)).copy(), np.ctypeslib.as_array(dirs, (3,)).copy())
-                if r is None:
-                    return 0
-                out[0], out[1], out[2] = float(r[0]), float(r[1]), float(r[2])
-                return 1
-
-            def _deflect(_user, prim, pos, dirs, out):
-                r = host_deflect(int(prim), np.ctypeslib.as_array(pos, (3,)).copy(), np.ctypeslib.as_array(dirs, (3,)).copy())
-                for k in range(9):
-                    out[k] = float(r[k])
-
-            self._cb = capi.HostCallbacks(capi.HIT_FN(_hit), capi.DEFLECT_FN(_deflect), None)   # kept alive with the scene
+            self._cb = host_callbacks(host_hit, host_deflect)   # kept alive with the scene
             check(capi.dll().mipt_scene_upload_host(ctx.h, C.byref(d), int(flags or 0), C.byref(self._cb), C.byref(h)), "mipt_scene_upload_host")
         elif flags is None:
             check(capi.dll().mipt_scene_upload(ctx.h, C.byref(d), C.byref(h)), "mipt_scene_upload")
@@ -214,6 +220,14 @@ class Context:
         check(capi.dll().mipt_sdf_eval(self.h, scene.h, int(prim), pos.shape[0], fp(pos), fp(out)), "mipt_sdf_eval")
         return out
 
+    def sdf_material_eval(self, scene, prim, pos):
+        """The material hits at (n, 3) local points of SDF primitive `prim` are shaded with: (n, 9) floats
+        {albedo rgb, emitted rgb, diffuse, specular, sharpness}."""
+        pos = f32(pos)
+        out = np.zeros((pos.shape[0], 9), np.float32)
+        check(capi.dll().mipt_sdf_material_eval(self.h, scene.h, int(prim), pos.shape[0], fp(pos), fp(out)), "mipt_sdf_material_eval")
+        return out
+
     def tonemap(self, kind, img):
         img = f32(img)
         h, w = img.shape[:2]
@@ -249,20 +263,29 @@ class Node:
         check(capi.dll().mipt_init_all(n, arr, NODE_SIMULATE if simulate else 0, C.byref(h)), "mipt_init_all")
         self.h = h
         self._scenes = []
+        self._keep = []
 
     def size(self):
         return int(capi.dll().mipt_node_size(self.h))
 
-    def upload(self, flat):
+    def upload(self, flat, host_hit=None, host_deflect=None):
         keep = [np.ascontiguousarray(flat.kind, np.uint32), f32(flat.fwd), f32(flat.inv), f32(flat.params),
                 np.ascontiguousarray(flat.material, np.uint32), f32(flat.materials), f32(flat.noise)]
         k, fwd, inv, par, mat, mats, noise = keep
         d = capi.SceneDesc(k.shape[0], k.ctypes.data_as(capi._u32p), fp(fwd), fp(inv), fp(par),
                            mat.ctypes.data_as(capi._u32p), mats.shape[0], fp(mats), fp(noise))
         s = C.c_void_p()
-        check(capi.dll().mipt_node_scene_upload(self.h, C.byref(d), C.byref(s)), "mipt_node_scene_upload")
+        if host_hit is not None:
+            cb = host_callbacks(host_hit, host_deflect)
+            self._keep.append(cb)   # the callbacks live as long as the node
+            check(capi.dll().mipt_node_scene_upload_host(self.h, C.byref(d), C.byref(cb), C.byref(s)), "mipt_node_scene_upload_host")
+        else:
+            check(capi.dll().mipt_node_scene_upload(self.h, C.byref(d), C.byref(s)), "mipt_node_scene_upload")
         self._scenes.append(s)
         return s
+
+    def ctx_handle(self, shard):
+        return capi.dll().mipt_node_ctx(self.h, int(shard))
 
     def render(self, scene, cam16, w, h, bounces, spp, seed=1, tonemap=-1, first_sample=0):
         cam = capi.make_camera(cam16)

@@ -66,8 +66,8 @@ EXPORTS = [
     "mipt_scene_free", "mipt_scene_info", "mipt_render", "mipt_render_accumulate", "mipt_scale_device",
     "mipt_primary_hits", "mipt_trace_rays", "mipt_tonemap", "mipt_tonemap_device", "mipt_affine_inverse",
     "mipt_rotation", "mipt_affine_mul", "mipt_noise_transform", "mipt_world_bounds", "mipt_present_rgba8",
-    "mipt_tonemap_device_noalloc", "mipt_trim", "mipt_sdf_eval", "mipt_set_counting", "mipt_device_floats_write", "mipt_scene_upload_host", "mipt_add_device", "mipt_init_all", "mipt_node_shutdown", "mipt_node_size", "mipt_node_ctx",
-    "mipt_node_cancel", "mipt_node_scene_upload", "mipt_node_scene_free", "mipt_node_render",
+    "mipt_tonemap_device_noalloc", "mipt_trim", "mipt_sdf_eval", "mipt_sdf_material_eval", "mipt_set_counting", "mipt_device_floats_write", "mipt_scene_upload_host", "mipt_add_device", "mipt_init_all", "mipt_node_shutdown", "mipt_node_size", "mipt_node_ctx",
+    "mipt_node_cancel", "mipt_node_scene_upload", "mipt_node_scene_upload_host", "mipt_node_scene_free", "mipt_node_render",
 ]
 
 _dll = None
@@ -101,6 +101,7 @@ def dll():
         d.mipt_node_ctx.restype = C.c_void_p
         d.mipt_node_cancel.argtypes = [C.c_void_p]
         d.mipt_node_scene_upload.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+        d.mipt_node_scene_upload_host.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.c_void_p, C.POINTER(C.c_void_p)]
         d.mipt_node_scene_free.argtypes = [C.c_void_p, C.c_void_p]
         d.mipt_node_scene_free.restype = None
         d.mipt_node_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Camera), C.POINTER(Settings), C.c_int, _f32p, C.POINTER(Stats)]
@@ -119,6 +120,7 @@ def dll():
         d.mipt_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, _i32p, _f32p]
         d.mipt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, _f32p, _f32p, C.c_uint32, C.c_uint64, _f32p, _i32p, _f32p]
         d.mipt_sdf_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _f32p, _f32p]
+        d.mipt_sdf_material_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, _f32p, _f32p]
         d.mipt_tonemap.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, C.c_size_t, C.c_size_t]
         d.mipt_tonemap_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         d.mipt_tonemap_device_noalloc.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]

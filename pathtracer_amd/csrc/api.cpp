@@ -1452,17 +1452,44 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     return MIPT_OK;
 }
 
+// Argument check of the SDF probes (caller holds the context's lock): an SDF primitive with a device form, and for
+// the kinds that run noise() octave by octave a scene that carries the noise transform.
+static int check_sdf_probe(const mipt_scene* sc, uint32_t prim) {
+    if (prim >= sc->dev.n_prims || prim >= sc->kinds.size()) return MIPT_ERR_ARGUMENT;
+    const uint32_t kind = sc->kinds[prim];
+    if (kind < MIPT_CRATERBALL || kind > MIPT_WEIRDWALL) return MIPT_ERR_ARGUMENT;   // analytic, or evaluated on the host
+    if (kind >= MIPT_ROUGHBOX && !sc->dev.noise_raw) return MIPT_ERR_ARGUMENT;
+    if (kind == MIPT_CRATERBALL && (!sc->dev.noise_oct || !sc->dev.craters)) return MIPT_ERR_ARGUMENT;
+    return MIPT_OK;
+}
+
 int mipt_sdf_eval(mipt_ctx* c, const mipt_scene* sc, uint32_t prim, uint32_t n, const float* pos3, float* out) {
     if (!c || !sc || !pos3 || !out || n == 0) return MIPT_ERR_ARGUMENT;
     if (n > (1u << 28)) return MIPT_ERR_TOO_LARGE;
-    if (prim >= sc->dev.n_prims || sc->kinds[prim] < MIPT_CRATERBALL) return MIPT_ERR_ARGUMENT;   // not an SDF primitive
     std::lock_guard<std::mutex> lock(c->mutex);
+    if (const int rc = check_sdf_probe(sc, prim); rc != MIPT_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     const int rc = ensure_floats(c, &c->stage, &c->stage_cap, static_cast<size_t>(n) * 4);
     if (rc != MIPT_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->stage, pos3, static_cast<size_t>(n) * 12, hipMemcpyHostToDevice, c->stream));
     launch_sdf_eval(c->stream, sc->dev, prim, c->lane_threshold, c->stage, n, c->stage + static_cast<size_t>(n) * 3);
     HIP_TRY(c, hipMemcpyAsync(out, c->stage + static_cast<size_t>(n) * 3, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return MIPT_OK;
+}
+
+int mipt_sdf_material_eval(mipt_ctx* c, const mipt_scene* sc, uint32_t prim, uint32_t n, const float* pos3, float* out9) {
+    if (!c || !sc || !pos3 || !out9 || n == 0) return MIPT_ERR_ARGUMENT;
+    if (n > (1u << 24)) return MIPT_ERR_TOO_LARGE;
+    std::lock_guard<std::mutex> lock(c->mutex);
+    if (const int rc = check_sdf_probe(sc, prim); rc != MIPT_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int rc = ensure_floats(c, &c->stage, &c->stage_cap, static_cast<size_t>(n) * 12);
+    if (rc != MIPT_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->stage, pos3, static_cast<size_t>(n) * 12, hipMemcpyHostToDevice, c->stream));
+    launch_sdf_material(c->stream, sc->dev, prim, c->stage, n, c->stage + static_cast<size_t>(n) * 3);
+    HIP_TRY(c, hipMemcpyAsync(out9, c->stage + static_cast<size_t>(n) * 3, static_cast<size_t>(n) * 36, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     return MIPT_OK;

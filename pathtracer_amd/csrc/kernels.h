@@ -86,6 +86,8 @@ void launch_crater_cells(hipStream_t, const float off[3], const int base[3], int
 void launch_sdf_march(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t round);
 // signed distance of SDF primitive `prim` at n points of its local frame (device arrays)
 void launch_sdf_eval(hipStream_t, const SceneDev&, uint32_t prim, uint32_t lane_threshold, const float* pos3, uint32_t n, float* out);
+// the material a hit at each of n local points of SDF primitive `prim` is shaded with (9 floats per point; device arrays)
+void launch_sdf_material(hipStream_t, const SceneDev&, uint32_t prim, const float* pos3, uint32_t n, float* out9);
 void launch_shade(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, uint32_t max_bounces);
 void launch_shade_sdf(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, uint32_t max_bounces);
 // ---- objects evaluated on the host (kind 8) ---------------------------------------------------------------

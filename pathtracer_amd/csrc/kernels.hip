@@ -1846,6 +1846,81 @@ __global__ void __launch_bounds__(256) k_host_apply(PathBuffers pb, uint32_t n, 
     pending_flush(survivors, &pb.counters[bounce + 1].n_live, next_queue);
 }
 
+// ---- the lane-evaluated SDF kinds' normals and per-hit materials, shared by shading and the parity probe ----------
+// Forward-difference normal (signedDistanceNormal, include/Object.hpp:118-132) of a lane-evaluated object at `base`,
+// by the four lanes of a quad: lane e of the quad evaluates point e (all four lanes call with the same arguments).
+__device__ __forceinline__ f3 plain_quad_normal(uint32_t plain, f3 prm, const float* noise_raw, f3 base, uint32_t e) {
+    const float delta = 1e-3f;
+    const f3 q = mk3(base.x + (e == 1u ? delta : 0.0f), base.y + (e == 2u ? delta : 0.0f), base.z + (e == 3u ? delta : 0.0f));
+    const float w = plain_sdf(plain, prm, noise_raw, q);
+    const float w0 = dpp_f<0x00>(0.0f, w), w1 = dpp_f<0x55>(0.0f, w), w2 = dpp_f<0xAA>(0.0f, w), w3 = dpp_f<0xFF>(0.0f, w);
+    return unit(mk3(w1 - w0, w2 - w0, w3 - w0) * (1.0f / delta));
+}
+// The normals a hit at `local_hit` needs: the surface normal and, for RoughSphereObject, whose material is made of
+// normals at two other points (PathTracerDemo.cpp:187-188), those two.  Quad-cooperative like plain_quad_normal.
+struct PlainNormals {
+    f3 n, n1, n2;
+};
+__device__ __forceinline__ PlainNormals plain_normals(uint32_t plain, f3 prm, const float* noise_raw, f3 local_hit, uint32_t e) {
+    PlainNormals r;
+    r.n = plain_quad_normal(plain, prm, noise_raw, local_hit, e);
+    r.n1 = r.n2 = mk3(0, 0, 0);
+    if (plain == 6u) {
+        r.n1 = plain_quad_normal(plain, prm, noise_raw, (-local_hit) * 1.724674f + mk3(3.474577f, 1.734674f, 2.713652f), e);
+        r.n2 = plain_quad_normal(plain, prm, noise_raw, local_hit * 2.446744f + mk3(1.734674f, 2.713652f, 4.137371f), e);
+    }
+    return r;
+}
+// The procedural materials of PathTracerDemo.cpp:184-199 (RoughSphereObject), 248-259 (RoughBoxObject), 330-341
+// (WeirdWallObject): what the object's deflectLocalRay makes of its `material` member at this hit.
+__device__ __forceinline__ void plain_material(uint32_t plain, const PlainNormals& pn, f3 local_hit, MaterialRec& mat) {
+    f3 a;
+    if (plain == 6u) {
+        a = mk3(0.5f, 0.5f, 0.5f) + 0.5f * pn.n1;
+        const f3 n2 = mk3(0.5f, 0.5f, 0.5f) + 0.5f * pn.n2;
+        mat.diffuse = n2.x;
+        mat.specular = 1.0f - n2.x;
+        mat.sharpness = n2.y;
+        const float k = 0.125f * n2.z;
+        mat.emitted[0] = k * a.x;
+        mat.emitted[1] = k * a.y;
+        mat.emitted[2] = k * a.z;
+    } else {
+        a = foam_albedo(local_hit, plain == 5u ? 0.2f : 0.018347f);
+    }
+    mat.albedo[0] = a.x;
+    mat.albedo[1] = a.y;
+    mat.albedo[2] = a.z;
+}
+
+// Parity probe: the material a hit at each of n local points of SDF primitive `prim` is shaded with -- 9 floats per point
+// {reflected absorption r g b, emitted luminance r g b, diffuse, specular, sharpness} -- through the code shading uses.
+// One quad per point.
+__global__ void __launch_bounds__(256) k_sdf_material(SceneDev sc, uint32_t prim, const float* pos3, uint32_t n, float* out9) {
+    const PrimRec* pr = sc.prims + prim;
+    const uint32_t kind = pr->kind, plain = kind >= 5u ? kind : 0u;
+    const f3 prm = mk3(pr->p[0], pr->p[1], pr->p[2]);
+    const uint32_t e = threadIdx.x & 3u;
+    const uint32_t quads = (gridDim.x * blockDim.x) >> 2;
+    const uint32_t rounds = (n + quads - 1u) / quads;   // whole quads run every round: the normals are quad-cooperative
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = r * quads + ((blockIdx.x * blockDim.x + threadIdx.x) >> 2);
+        const bool valid = i < n;
+        const f3 p = valid ? mk3(pos3[3 * i], pos3[3 * i + 1], pos3[3 * i + 2]) : mk3(0.1f, 0.2f, 0.3f);
+        MaterialRec mat = sc.materials[pr->material];
+        if (plain) {
+            const PlainNormals pn = plain_normals(plain, prm, sc.noise_raw, p, e);
+            plain_material(plain, pn, p, mat);
+        }
+        if (valid && e == 0u) {
+            float* o = out9 + 9 * static_cast<size_t>(i);
+            o[0] = mat.albedo[0]; o[1] = mat.albedo[1]; o[2] = mat.albedo[2];
+            o[3] = mat.emitted[0]; o[4] = mat.emitted[1]; o[5] = mat.emitted[2];
+            o[6] = mat.diffuse; o[7] = mat.specular; o[8] = mat.sharpness;
+        }
+    }
+}
+
 // SDF hits: the normal is a forward difference of four SDF evaluations (signedDistanceNormal,
 // include/Object.hpp:118-132): at the hit and at +delta along x, y, z.  The four lanes of a quad take
 // the four points of one hit, so a wave shades 16 hits per round; the quad's first lane then deflects
@@ -1907,20 +1982,10 @@ __device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchPa
         float v = s;
         // Lane-evaluated kinds: each lane of the quad evaluates its own point of the forward difference
         // (a quad shares one hit, so the branch is uniform over the quad and the broadcasts are safe).
-        f3 plain_n = mk3(0, 0, 1), plain_n1 = mk3(0, 0, 0), plain_n2 = mk3(0, 0, 0);
+        PlainNormals pn{mk3(0, 0, 1), mk3(0, 0, 0), mk3(0, 0, 0)};
         if (PLAIN && plain) {
-            const auto quad_normal = [&](f3 base) {
-                const f3 q = mk3(base.x + (e == 1u ? delta : 0.0f), base.y + (e == 2u ? delta : 0.0f), base.z + (e == 3u ? delta : 0.0f));
-                const float w = plain_sdf(plain, off, sc.noise_raw, q);
-                const float w0 = dpp_f<0x00>(0.0f, w), w1 = dpp_f<0x55>(0.0f, w), w2 = dpp_f<0xAA>(0.0f, w), w3 = dpp_f<0xFF>(0.0f, w);
-                return unit(mk3(w1 - w0, w2 - w0, w3 - w0) * (1.0f / delta));
-            };
-            plain_n = quad_normal(local_hit);
-            if (plain == 6u) {   // RoughSphereObject's material is made of normals at two other points (PathTracerDemo.cpp:187-188)
-                plain_n1 = quad_normal((-local_hit) * 1.724674f + mk3(3.474577f, 1.734674f, 2.713652f));
-                plain_n2 = quad_normal(local_hit * 2.446744f + mk3(1.734674f, 2.713652f, 4.137371f));
-                c_evals += 2;
-            }
+            pn = plain_normals(plain, off, sc.noise_raw, local_hit, e);
+            if (plain == 6u) c_evals += 2;
         }
         wave_near(sc.craters, sc.crater_masks, crater_regs, cl, lds, lane, bp.lane_threshold, wants, p, off, s, crater_base, crater_count, v, c_near, c_noise);
         const float v0 = dpp_f<0x00>(0.0f, v), v1 = dpp_f<0x55>(0.0f, v), v2 = dpp_f<0xAA>(0.0f, v), v3 = dpp_f<0xFF>(0.0f, v);   // quad broadcasts
@@ -1930,7 +1995,7 @@ __device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchPa
             if (fractal) {
                 nrm = fractal_normal(local_hit);   // six cheap evaluations on the quad's first lane
             } else if (PLAIN && plain) {
-                nrm = plain_n;
+                nrm = pn.n;
             } else {
                 const f3 g = mk3(v1 - v0, v2 - v0, v3 - v0) * (1.0f / delta);
                 nrm = unit(g);
@@ -1941,25 +2006,9 @@ __device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchPa
             const uint32_t bounce = round - lag;
             Rng rng(bp.seed, py * bp.width + px, bp.first_sample + s_local, 1u + bounce);
             Bounce b;
-            if (PLAIN && plain) {   // the procedural materials of PathTracerDemo.cpp:184-199, 248-259, 330-341
+            if (PLAIN && plain) {
                 MaterialRec mat = sc.materials[pr.material];
-                f3 a;
-                if (plain == 6u) {
-                    a = mk3(0.5f, 0.5f, 0.5f) + 0.5f * plain_n1;
-                    const f3 n2 = mk3(0.5f, 0.5f, 0.5f) + 0.5f * plain_n2;
-                    mat.diffuse = n2.x;
-                    mat.specular = 1.0f - n2.x;
-                    mat.sharpness = n2.y;
-                    const float k = 0.125f * n2.z;
-                    mat.emitted[0] = k * a.x;
-                    mat.emitted[1] = k * a.y;
-                    mat.emitted[2] = k * a.z;
-                } else {
-                    a = foam_albedo(local_hit, plain == 5u ? 0.2f : 0.018347f);
-                }
-                mat.albedo[0] = a.x;
-                mat.albedo[1] = a.y;
-                mat.albedo[2] = a.z;
+                plain_material(plain, pn, local_hit, mat);
                 b = deflect(mat, ld, nrm, rng);
             } else {
                 b = deflect(sc.materials[pr.material], ld, nrm, rng);
@@ -2254,6 +2303,10 @@ void launch_sdf_march(hipStream_t st, const SceneDev& sc, const BatchParams& bp,
 
 void launch_sdf_eval(hipStream_t st, const SceneDev& sc, uint32_t prim, uint32_t lane_threshold, const float* pos3, uint32_t n, float* out) {
     hipLaunchKernelGGL(k_sdf_eval, dim3(grid_for(n, 256u * 4u)), dim3(256), 0, st, sc, prim, lane_threshold, pos3, n, out);
+}
+
+void launch_sdf_material(hipStream_t st, const SceneDev& sc, uint32_t prim, const float* pos3, uint32_t n, float* out9) {
+    hipLaunchKernelGGL(k_sdf_material, dim3(grid_for(static_cast<size_t>(n) * 4u, 256u * 4u)), dim3(256), 0, st, sc, prim, pos3, n, out9);
 }
 
 void launch_shade(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, uint32_t max_bounces) {

@@ -160,6 +160,10 @@ int mipt_node_cancel(mipt_node* node) {
 }
 
 int mipt_node_scene_upload(mipt_node* node, const mipt_scene_desc* desc, mipt_node_scene** out) {
+    return mipt_node_scene_upload_host(node, desc, nullptr, out);
+}
+
+int mipt_node_scene_upload_host(mipt_node* node, const mipt_scene_desc* desc, const mipt_host_callbacks* cb, mipt_node_scene** out) {
     if (!node || !desc || !out) return MIPT_ERR_ARGUMENT;
     *out = nullptr;
     auto* ns = new (std::nothrow) mipt_node_scene;
@@ -176,7 +180,8 @@ int mipt_node_scene_upload(mipt_node* node, const mipt_scene_desc* desc, mipt_no
             ns->scene[i] = ns->scene[first];   // shards of one device read the same upload
             continue;
         }
-        const int rc = mipt_scene_upload(node->ctx[i], desc, &ns->scene[i]);
+        // (objects without a device form are evaluated by the caller's callbacks from every shard's host threads at once)
+        const int rc = cb ? mipt_scene_upload_host(node->ctx[i], desc, 0u, cb, &ns->scene[i]) : mipt_scene_upload(node->ctx[i], desc, &ns->scene[i]);
         if (rc != MIPT_OK) {
             mipt_node_scene_free(node, ns);
             return rc;

@@ -659,6 +659,14 @@ struct SceneDeviceState {
     // objects without a device form, by primitive index (null for device primitives): evaluated through their own
     // virtuals by the callbacks below
     std::vector<const Object*> host_objects;
+    // device twins of SDF objects that have been checked against the object's own signedDistance (twin_matches)
+    struct TwinVerdict {
+        const Object* object;
+        int kind;
+        float params[9], noise[12], material[14];
+        bool ok;
+    };
+    std::vector<TwinVerdict> twin_cache;
     ~SceneDeviceState() {
         if (scene) mipt_scene_free(scene);
         if (node_scene) mipt_node_scene_free(node, node_scene);
@@ -731,6 +739,128 @@ void host_object_deflect(void* user, uint32_t prim, const float pos[3], const fl
 }
 }   // namespace
 
+// Is the device twin that `d` names the class this object really is?  A demo class is recognised by its name and size
+// (describeKnownDemoSdf), and a program is free to change what a class of that name computes (include/Object.hpp:107-177
+// lets Derived::signedDistance and deflectLocalRay be anything): the device would go on rendering the formula it knows.
+// So before a twin is used, the object's own signedDistance is compared with the device's (mipt_sdf_eval) at several
+// hundred points of its local box -- short sphere-traced walks towards the surface, so that most of them lie in the
+// near field, plus points spread over the box -- and its deflectRay with the device's per-hit material
+// (mipt_sdf_material_eval) at the walks' ends.  One primitive, identity transform, on the shared context.
+bool twin_matches(const Object& object, const DevicePrimitive& d, const float noise[12], const char** why) {
+    static std::string reason;
+    std::uint32_t rng = 0x9e3779b9u;
+    const auto u01 = [&rng]() {
+        rng = rng * 1664525u + 1013904223u;
+        return static_cast<float>(rng >> 8) * (1.0f / 16777216.0f);
+    };
+    const float* bc = d.probe_box;
+    const float* bh = d.probe_box + 3;
+    const auto in_box = [&](const float p[3]) {
+        return std::abs(p[0] - bc[0]) <= bh[0] && std::abs(p[1] - bc[1]) <= bh[1] && std::abs(p[2] - bc[2]) <= bh[2];
+    };
+    std::vector<float> pts, want, ends;
+    const auto visit = [&](const float p[3]) {
+        const float v = d.probe_sdf(d.probe_object, p);
+        pts.insert(pts.end(), p, p + 3);
+        want.push_back(v);
+        return v;
+    };
+    for (int walk = 0; walk < 48; ++walk) {
+        // from a point of the box's surface towards a point near its centre
+        float p[3], target[3], dir[3];
+        const int face = static_cast<int>(u01() * 6.0f) % 6;
+        for (int k = 0; k < 3; ++k) {
+            p[k] = bc[k] + bh[k] * (2.0f * u01() - 1.0f);
+            target[k] = bc[k] + 0.3f * bh[k] * (2.0f * u01() - 1.0f);
+        }
+        p[face / 2] = bc[face / 2] + ((face & 1) ? bh[face / 2] : -bh[face / 2]) * 0.999f;
+        float len = 0.0f;
+        for (int k = 0; k < 3; ++k) {
+            dir[k] = target[k] - p[k];
+            len += dir[k] * dir[k];
+        }
+        len = std::sqrt(len);
+        if (!(len > 0.0f)) continue;
+        for (int k = 0; k < 3; ++k) dir[k] /= len;
+        for (int step = 0; step < 14 && in_box(p); ++step) {
+            const float v = visit(p);
+            if (!(std::abs(v) <= 3.0e38f)) break;
+            if (std::abs(v) < 2e-4f) {
+                ends.insert(ends.end(), p, p + 3);
+                break;
+            }
+            const float adv = std::max(std::abs(v), 1e-3f);
+            for (int k = 0; k < 3; ++k) p[k] += adv * dir[k];
+        }
+    }
+    for (int k = 0; k < 128; ++k) {
+        const float p[3] = {bc[0] + bh[0] * (2.0f * u01() - 1.0f), bc[1] + bh[1] * (2.0f * u01() - 1.0f), bc[2] + bh[2] * (2.0f * u01() - 1.0f)};
+        visit(p);
+    }
+    // the twin, alone in a scene of its own
+    const std::uint32_t kind = static_cast<std::uint32_t>(d.kind), material = 0;
+    const float identity[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    mipt_scene_desc desc{};
+    desc.n_prims = 1;
+    desc.kind = &kind;
+    desc.fwd = identity;
+    desc.inv = identity;
+    desc.params = d.params;
+    desc.material = &material;
+    desc.n_materials = 1;
+    desc.materials = d.material->record();
+    desc.noise_transform = noise;
+    mipt_scene* twin = nullptr;
+    int rc = mipt_scene_upload(shared_context(), &desc, &twin);
+    if (rc != MIPT_OK) fail("mipt_scene_upload (device twin check)", rc);
+    const std::uint32_t n = static_cast<std::uint32_t>(want.size());
+    std::vector<float> got(n);
+    rc = mipt_sdf_eval(shared_context(), twin, 0, n, pts.data(), got.data());
+    if (rc != MIPT_OK) fail("mipt_sdf_eval (device twin check)", rc);
+    std::uint32_t off = 0;
+    float worst = 0.0f;
+    for (std::uint32_t i = 0; i < n; ++i) {
+        const float diff = std::abs(got[i] - want[i]);
+        if (!(diff <= 2e-5f * std::max(1.0f, std::abs(want[i])))) ++off;
+        if (diff > worst || diff != diff) worst = diff;
+    }
+    bool ok = off * 100u <= n;   // a point on a crater's rim or a cell wall may fall on the other side in float arithmetic
+    if (!ok) reason = "signedDistance differs from the device's at " + std::to_string(off) + " of " + std::to_string(n) + " probe points (largest difference " + std::to_string(worst) + ")";
+    // the per-hit material, where the walks ended on the surface: struck from outside along the inward normal, every
+    // lobe of BasicMaterial::deflect returns the material's emission and reflected absorption (src/BasicMaterial.cpp:123-159)
+    const std::uint32_t n_hits = static_cast<std::uint32_t>(ends.size() / 3);
+    if (ok && n_hits) {
+        std::vector<float> mats(static_cast<std::size_t>(n_hits) * 9);
+        rc = mipt_sdf_material_eval(shared_context(), twin, 0, n_hits, ends.data(), mats.data());
+        if (rc != MIPT_OK) fail("mipt_sdf_material_eval (device twin check)", rc);
+        std::uint32_t bad = 0;
+        const Affine& T = object.transformation();
+        for (std::uint32_t i = 0; i < n_hits; ++i) {
+            const float* p = &ends[3 * static_cast<std::size_t>(i)];
+            const float delta = 1e-3f, v0 = d.probe_sdf(d.probe_object, p);
+            float g[3];
+            for (int k = 0; k < 3; ++k) {
+                float q[3] = {p[0], p[1], p[2]};
+                q[k] += delta;
+                g[k] = d.probe_sdf(d.probe_object, q) - v0;
+            }
+            const Vec nrm = Vec(g[0], g[1], g[2]).unit();
+            if (!(nrm.x == nrm.x)) continue;
+            const ColorBounce b = object.deflectRay(Ray(T * (-1.0f * nrm), T * Pos(p[0], p[1], p[2])));
+            const float* m = &mats[9 * static_cast<std::size_t>(i)];
+            const float host6[6] = {b.attenuation.r, b.attenuation.g, b.attenuation.b, b.emitted.r, b.emitted.g, b.emitted.b};
+            bool same = true;
+            for (int k = 0; k < 6; ++k) same = same && std::abs(host6[k] - m[k]) <= 0.02f * std::max(1.0f, std::abs(host6[k]));
+            bad += same ? 0u : 1u;
+        }
+        ok = bad * 4u <= n_hits;   // forward-difference normals and cell-wall points: a few hits may disagree
+        if (!ok) reason = "deflectLocalRay's material differs from the device's at " + std::to_string(bad) + " of " + std::to_string(n_hits) + " probe hits";
+    }
+    mipt_scene_free(twin);
+    if (why) *why = reason.c_str();
+    return ok;
+}
+
 // Flattens the objects (Scene::updateGeometry's job in this design) and uploads when anything changed.
 // The caller holds the scene's device-state lock until it has finished rendering from the returned scene.
 mipt_scene* sync_scene(const Scene& scene, mipt_node* node = nullptr) {
@@ -744,10 +874,41 @@ mipt_scene* sync_scene(const Scene& scene, mipt_node* node = nullptr) {
     const float* own_noise = nullptr;
     std::vector<const Object*> host_objects(n, nullptr);
     bool any_host = false;
+    static const bool check_twins = !(std::getenv("MIPT_TRUST_TWINS") && std::atoi(std::getenv("MIPT_TRUST_TWINS")) != 0);
     static const BasicMaterial unused_material;   // the material row of a host-evaluated object is never read
     for (std::size_t i = 0; i < n; ++i) {
         DevicePrimitive d;
         objs[i]->describeForDevice(d);
+        if (d.kind >= 0 && d.material && d.probe_sdf && check_twins) {
+            // a device twin of an SDF class: trusted once it has been seen to compute what the object computes
+            float nz[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+            if (d.noise) std::memcpy(nz, d.noise, sizeof(nz));
+            else if (&noiseTransform) affine_to(noiseTransform(), nz);
+            const SceneDeviceState::TwinVerdict* known = nullptr;
+            for (const auto& v : st.twin_cache)
+                if (v.object == objs[i].get() && v.kind == d.kind && std::memcmp(v.params, d.params, sizeof(v.params)) == 0 &&
+                    std::memcmp(v.noise, nz, sizeof(nz)) == 0 && std::memcmp(v.material, d.material->record(), sizeof(v.material)) == 0)
+                    known = &v;
+            bool ok;
+            if (known) {
+                ok = known->ok;
+            } else {
+                const char* why = "";
+                ok = twin_matches(*objs[i], d, nz, &why);
+                SceneDeviceState::TwinVerdict v{};
+                v.object = objs[i].get();
+                v.kind = d.kind;
+                std::memcpy(v.params, d.params, sizeof(v.params));
+                std::memcpy(v.noise, nz, sizeof(nz));
+                std::memcpy(v.material, d.material->record(), sizeof(v.material));
+                v.ok = ok;
+                st.twin_cache.push_back(v);
+                if (!ok)
+                    std::fprintf(stderr, "pathtracer: %s has the name of a class the device knows, but it is not that class: its %s.  It is evaluated by its own "
+                                         "virtuals on the host.\n", d.type_name, why);
+            }
+            if (!ok) d.kind = -1;
+        }
         if (d.kind < 0 || !d.material) {
             // Any other Object subclass (the reference lets a user override hitLocalRay / deflectLocalRay / getLocalBoundingBox,
             // include/Object.hpp:45-52): no device form -- rays that reach its world box are evaluated by the object's own
@@ -803,17 +964,18 @@ mipt_scene* sync_scene(const Scene& scene, mipt_node* node = nullptr) {
     desc.noise_transform = noise;
     st.host_objects = std::move(host_objects);
     int rc;
-    if (node) {
-        if (any_host) fail("Renderer::render on several GPUs (MIPT_GPUS): the scene holds an object without a device form, which only the single-GPU path evaluates", MIPT_ERR_ARGUMENT);
-        st.node = node;
-        rc = mipt_node_scene_upload(node, &desc, &st.node_scene);
-    } else if (any_host) {
+    const mipt_host_callbacks host_cb{host_object_hit, host_object_deflect, &st};
+    if (any_host) {
         std::size_t count = 0;
         for (const Object* o : st.host_objects) count += o ? 1 : 0;
         std::fprintf(stderr, "pathtracer: %zu object(s) of this scene have no device form (first: %s); their rays are evaluated by their own virtuals on the "
                              "host between the GPU stages -- the slow path\n", count, typeid(**std::find_if(st.host_objects.begin(), st.host_objects.end(), [](const Object* o) { return o != nullptr; })).name());
-        const mipt_host_callbacks cb{host_object_hit, host_object_deflect, &st};
-        rc = mipt_scene_upload_host(shared_context(), &desc, std::getenv("MIPT_DEVICE_BVH") && std::atoi(std::getenv("MIPT_DEVICE_BVH")) ? static_cast<uint32_t>(MIPT_UPLOAD_DEVICE_BVH) : 0u, &cb,
+    }
+    if (node) {
+        st.node = node;
+        rc = mipt_node_scene_upload_host(node, &desc, any_host ? &host_cb : nullptr, &st.node_scene);
+    } else if (any_host) {
+        rc = mipt_scene_upload_host(shared_context(), &desc, std::getenv("MIPT_DEVICE_BVH") && std::atoi(std::getenv("MIPT_DEVICE_BVH")) ? static_cast<uint32_t>(MIPT_UPLOAD_DEVICE_BVH) : 0u, &host_cb,
                                     &st.scene);
     } else {
         rc = mipt_scene_upload(shared_context(), &desc, &st.scene);

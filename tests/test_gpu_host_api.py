@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "pathtracer_amd", "lib")
 HARNESS = os.path.join(LIB, "libhost_harness.so")
 HARNESS_DEMO = os.path.join(ROOT, "oracle", "_ref", "libhost_harness_demo.so")
+HARNESS_DEMO_EDITED = os.path.join(ROOT, "oracle", "_ref", "libhost_harness_demo_edited.so")
+REF_EDITED = os.path.join(ROOT, "oracle", "_ref", "libref_edited.so")
 DEFAULT_SEED = 0x5EED   # Renderer's seed until setSeed is called
 
 
@@ -90,6 +92,47 @@ def test_unchanged_demo_classes_render_on_the_gpu(ctx):
         want, st = ctx.render(ctx.upload(flat), cam, 32, 32, 4, 2, seed=DEFAULT_SEED)
         assert st["sdf_shades"] > 100
         assert np.array_equal(got, want)
+
+
+def test_an_edited_demo_class_is_not_mistaken_for_its_device_twin(ctx, capfd):
+    """The demo file is a playground: a program may change what CraterBallObject::signedDistance computes and keep the
+    class's name and size (include/Object.hpp:107-177 lets Derived::signedDistance be anything).  Both harnesses below
+    are built from the reference's demo block with ONE constant changed on the way through the pipe (the sphere's
+    radius, 0.5 -> 0.42; oracle/Makefile): libref_edited.so is the reference's own renderer with that class,
+    libhost_harness_demo_edited.so the same block compiled against this repository's headers.  The scene flattening
+    must find that the device's twin does not compute what the object computes (probe points through
+    mipt_sdf_eval), say so, and evaluate the object through its own virtuals: the frame then matches the reference's
+    frame of the EDITED class, which the device twin's frame does not."""
+    if not (os.path.exists(HARNESS_DEMO_EDITED) and os.path.exists(REF_EDITED)):
+        pytest.skip("the edited-class harnesses are not built (need the reference checkout at build time)")
+    host, ref = orc.Reference(HARNESS_DEMO_EDITED), orc.Reference(REF_EDITED)
+    noise = host.init_noise(G.NOISE_SEED)
+    assert np.array_equal(noise, ref.init_noise(G.NOISE_SEED))
+    alg = api.HostAlgebra()
+    flat = S.demo_scene(alg, noise)
+    cam = G.demo_closeup_camera(alg)
+    # the edited class itself: the same values from either build, and not the device twin's
+    rs = np.random.RandomState(1)
+    d = rs.normal(size=(500, 3))
+    pts = (d / np.linalg.norm(d, axis=1)[:, None] * rs.uniform(0.45, 0.58, (500, 1))).astype(np.float32)
+    own = host.sdf_craterball(flat.params[0, :3], pts)
+    assert np.array_equal(own, ref.sdf_craterball(flat.params[0, :3], pts))
+    assert np.median(np.abs(own - ctx.sdf_eval(ctx.upload(flat), 0, pts))) > 0.05
+    w = h = 48
+    capfd.readouterr()
+    got = host.scene(flat).render(cam, w, h, 4, 32, seed=1, threads=1)
+    said = capfd.readouterr().err
+    assert "is not that class" in said and "evaluated by its own virtuals on the host" in said, said
+    a = ref.scene(flat).render(cam, w, h, 4, 32, seed=1001, threads=1)
+    b = ref.scene(flat).render(cam, w, h, 4, 32, seed=2002, threads=1)
+    twin, _ = ctx.render(ctx.upload(flat), cam, w, h, 4, 32, seed=5)   # what the device's CraterBallObject renders
+    rmse = lambda x, y: float(np.sqrt(np.mean((x - y) ** 2)))
+    floor = rmse(a, b)
+    print(f"edited class: RMSE host path / reference {rmse(got, a):.4f}, reference seeds {floor:.4f}, device twin / reference {rmse(twin, a):.4f}; "
+          f"means {got.mean():.4f} / {a.mean():.4f} / {twin.mean():.4f}")
+    assert floor > 0 and rmse(got, a) <= 1.25 * floor and rmse(got, b) <= 1.25 * floor
+    assert abs(got.mean() / (0.5 * (a.mean() + b.mean())) - 1.0) <= 0.05
+    assert rmse(twin, a) >= 1.8 * floor   # the statistic does tell the two classes apart
 
 
 def test_progressive_frame_keeps_the_accumulator_on_the_device(ctx, tmp_path):

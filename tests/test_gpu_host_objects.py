@@ -96,6 +96,45 @@ def test_host_objects_take_part_in_the_closest_hit_exactly(ctx, oracle):
     assert np.array_equal(wp, prim) and np.array_equal(wt[wp >= 0], t[wp >= 0])
 
 
+def test_host_objects_on_the_several_gpus_path(oracle):
+    """mipt_node_scene_upload_host: every shard of a node hands the rays that reach a host object to the same callbacks.
+    Three simulated shards on one GPU render the frame of the single context (the callbacks' deflect draws its own random
+    numbers, so the comparison is statistical) and report the summed host work."""
+    alg = api.HostAlgebra()
+    flat = G.sphere_box_scene(alg)
+    which = [int(np.flatnonzero(flat.kind == S.SPHERE)[0]), int(np.flatnonzero(flat.kind == S.BOX)[0])]
+    hosted, hit, deflect, calls = _as_host_objects(alg, flat, which, oracle)
+    cam = G.parity_camera(alg)
+    c = api.Context()
+    try:
+        want, _ = c.render(c.upload(flat), cam, 24, 24, 4, 24, seed=3)
+    finally:
+        c.close()
+    node = api.Node(devices=[0, 0, 0], simulate=True)
+    try:
+        ns = node.upload(hosted, host_hit=hit, host_deflect=deflect)
+        got, st = node.render(ns, cam, 24, 24, 4, 24, seed=3)
+        assert st["samples_done"] == 24 and st["host_rays"] > 0 and st["host_shades"] == calls["deflect"]
+        assert abs(got.mean() - want.mean()) <= 0.1 * want.mean(), (got.mean(), want.mean())
+    finally:
+        node.close()
+
+
+def test_sdf_probes_refuse_primitives_without_a_device_sdf(ctx, oracle):
+    """mipt_sdf_eval / mipt_sdf_material_eval: analytic primitives and host objects have no device SDF to ask."""
+    alg = api.HostAlgebra()
+    flat = G.sphere_box_scene(alg)
+    which = [int(np.flatnonzero(flat.kind == S.SPHERE)[0])]
+    hosted, hit, deflect, _ = _as_host_objects(alg, flat, which, oracle)
+    ds = ctx.upload(hosted, host_hit=hit, host_deflect=deflect)
+    pts = np.zeros((4, 3), np.float32)
+    for prim in (which[0], (which[0] + 1) % flat.n_prims, flat.n_prims):
+        for probe in (ctx.sdf_eval, ctx.sdf_material_eval):
+            with pytest.raises(api.MiptError) as e:
+                probe(ds, prim, pts)
+            assert e.value.status == -1
+
+
 def test_upload_refuses_host_objects_without_callbacks(ctx):
     alg = api.HostAlgebra()
     flat = S.cornell_scene(alg)

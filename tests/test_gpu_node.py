@@ -39,6 +39,31 @@ def test_simulated_shards_equal_the_single_gpu_frame(scene):
         node.close()
 
 
+def test_node_sums_the_counting_builds_fields():
+    """mipt_set_counting on every shard's context: the node's statistics carry the summed node visits and primitive
+    tests, equal to the single context's (the same rays walk the same tree)."""
+    alg = api.HostAlgebra()
+    flat, cam = S.random_scene(alg, 3000, seed=5), S.random_scene_camera(alg, 1.0)
+    ctx = api.Context()
+    try:
+        ctx.set_counting(True)
+        _, wst = ctx.render(ctx.upload(flat), cam, 64, 64, 4, 6, seed=2)
+    finally:
+        ctx.close()
+    assert wst["node_visits"] > 0 and wst["prim_tests"] > 0
+    node = api.Node(devices=[0, 0, 0], simulate=True)
+    try:
+        for shard in range(node.size()):
+            api.check(api.capi.dll().mipt_set_counting(node.ctx_handle(shard), 1), "mipt_set_counting")
+        _, st = node.render(node.upload(flat), cam, 64, 64, 4, 6, seed=2)
+        assert st["rays"] == wst["rays"]
+        for key in ("node_visits", "prim_tests"):   # (a second ray that starts over revisits nodes: scheduling may move these by a hair)
+            assert abs(st[key] - wst[key]) <= 0.01 * wst[key], (key, st[key], wst[key])
+        assert st["trav_rounds"] > 0 and st["trav_leaf_steps"] > 0
+    finally:
+        node.close()
+
+
 def test_one_rank_node_runs_the_rccl_all_reduce():
     alg = api.HostAlgebra()
     flat, cam = S.cornell_scene(alg), S.cornell_camera(alg)
