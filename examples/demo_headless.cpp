@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <thread>
 #include <vector>
 #include <string>
 
@@ -53,6 +54,9 @@ int main(int argc, char** argv) {
     const std::size_t passes = argc > 7 ? std::strtoul(argv[7], nullptr, 10) : 1;
     const std::size_t resume_after = argc > 8 ? std::strtoul(argv[8], nullptr, 10) : 0;
     const bool user_light = argc > 9 && std::string(argv[9]) == "user";
+    // "cancel:<ms>": one ProgressiveFrame pass that another thread cancels after <ms> milliseconds (Renderer::cancelRender
+    // as the demo's window thread calls it, PathTracerDemo.cpp:982); writes the mean of what had been accumulated
+    const bool cancel_mode = argc > 9 && std::string(argv[9]).rfind("cancel:", 0) == 0;
 
     // The demo draws its noise transform at random per process; fix it here.
     const Affine noise = Affine::Translation(Vec(0.417022f, 0.720324f, 0.000114f)) * Linear::RotationX(0.302333f) *
@@ -123,6 +127,25 @@ int main(int argc, char** argv) {
     auto renderer = Renderer{};
     renderer.startThreadPool();
     renderer.setSeed(seed);
+    if (cancel_mode) {
+        const long ms = std::strtol(argv[9] + 7, nullptr, 10);
+        ProgressiveFrame acc(width, height);
+        settings.setSamplesPerPixel(1);
+        acc.add(renderer, scene, camera, settings);   // a first pass, so that allocations and the scene upload are behind us
+        acc.reset();
+        renderer.setSeed(seed);
+        settings.setSamplesPerPixel(spp);
+        std::thread canceller([&] {
+            std::this_thread::sleep_for(std::chrono::milliseconds(ms));
+            renderer.cancelRender();
+        });
+        const bool finished = acc.add(renderer, scene, camera, settings);
+        canceller.join();
+        acc.image().save(out);
+        std::printf("pass %s: %llu samples per pixel counted, %zu passes, wrote %s\n", finished ? "finished" : "cancelled",
+                    static_cast<unsigned long long>(acc.samples()), acc.count(), out.c_str());
+        return 0;
+    }
     if (passes > 1) {
         ProgressiveFrame acc(width, height);
         std::vector<std::uint8_t> rgba(width * height * 4);

@@ -729,9 +729,12 @@ public:
     // forget what was accumulated (the demo's renderReset)
     void reset();
     // One more pass of settings.samplesPerPixel() samples, added on the device.  settings' size must be the frame's.
-    // Returns false when the pass was cancelled (Renderer::cancelRender): the frame then holds the sample batches that
-    // pass had finished, uncounted -- reset() it, as the demo does after every cancel (PathTracerDemo.cpp:976-990).
+    // Returns false when the pass was cancelled (Renderer::cancelRender): the sample batches that pass had finished are
+    // in the frame and counted (samples() says how many per pixel), so image() and present() still show a mean; the
+    // demo resets its accumulator after every cancel anyway (PathTracerDemo.cpp:976-990).
     bool add(Renderer&, const Scene&, const Camera&, const RenderSettings&);
+    // samples per pixel accumulated since the last reset
+    std::uint64_t samples() const noexcept { return m_samples; }
     // mean over everything accumulated, as the demo's `scaled`
     Image image() const;
     // copyToSFImage's bytes (PathTracerDemo.cpp:524-545: clamp to [0, 1], times 255, truncated; R, G, B, 255) of the mean,

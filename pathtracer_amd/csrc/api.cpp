@@ -972,9 +972,15 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
         bvh = build_bvh(std::move(boxes));
     }
     const uint32_t n_nodes = static_cast<uint32_t>(bvh.nodes.size());
+    // Before anything walks the tree on the host (the collapse recurses once per level, and a tree that came back from the
+    // device is not trusted blindly): a sane depth, and links that stay inside the arrays.
+    if (bvh.depth < 0 || bvh.depth > 60) return MIPT_ERR_TOO_LARGE;
+    for (const BvhNode& nd : bvh.nodes)
+        for (const int32_t link : {nd.child0, nd.child1})
+            if (link >= 0 ? static_cast<uint32_t>(link) >= n_nodes : static_cast<uint32_t>(~link) >= n) return MIPT_ERR_HIP;
     Bvh4Result bvh4 = collapse_bvh4(bvh.nodes.data(), bvh.nodes.size(), n);
     // the deepest traversal stack the kernels carry; only a great many coincident boxes get there
-    if (bvh.depth > 60 || bvh4.stack_need > kMaxTraversalStack) return MIPT_ERR_TOO_LARGE;
+    if (bvh4.stack_need > kMaxTraversalStack) return MIPT_ERR_TOO_LARGE;
     // the traversal addresses a node by a 32-bit byte offset (index * 128)
     if (bvh4.nodes.size() > (size_t(1) << 25)) return MIPT_ERR_TOO_LARGE;
 

@@ -1183,8 +1183,14 @@ bool ProgressiveFrame::add(Renderer& renderer, const Scene& scene, const Camera&
     mipt_scene* dev = mipt_host::sync_scene(scene);
     const mipt_camera cam = pack_camera(camera);
     const mipt_settings st = next_frame_settings(*renderer.m_state, settings);
-    const int rc = mipt_render_accumulate(ctx, dev, &cam, &st, m_device, nullptr);
-    if (rc == MIPT_ERR_CANCELLED) return false;
+    mipt_stats stats{};
+    const int rc = mipt_render_accumulate(ctx, dev, &cam, &st, m_device, &stats);
+    if (rc == MIPT_ERR_CANCELLED) {
+        // the sample batches that pass had finished are in the sums: they are counted, so that the mean stays a mean
+        m_samples += stats.samples_done;
+        m_count += stats.samples_done ? 1 : 0;
+        return false;
+    }
     if (rc != MIPT_OK) mipt_host::fail("mipt_render_accumulate", rc);
     m_samples += settings.samplesPerPixel();
     m_count += 1;

@@ -27,14 +27,16 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     roof = out["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof, key
-    assert roof["bound"] in ("hbm", "mfma")
-    assert roof["kernel"] == "k_sdf_march" and roof["peak"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    # the bound names the measured limiter: HBM, a matrix-core contraction, the L2s' gather rate, or (this kernel) vector instruction issue
+    assert roof["bound"] in ("hbm", "mfma", "l2", "valu")
+    assert roof["kernel"] == "k_sdf_march" and roof["bound"] == "valu" and roof["peak"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert 0.0 < roof["frac"] <= 1.0
     cpu = out["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
     # the GPU frame against the CPU reference frame at the same sample count (here 1 spp on a small frame: only the keys)
-    for key in ("gpu_vs_cpu", "cpu_seedA_vs_seedB", "box8_rel", "crop", "accepted"):
+    for key in ("gpu_vs_cpu", "cpu_seedA_vs_seedB", "box8_rel", "crop", "accepted", "accepted_rmse"):
         assert key in out["rmse"], key
 
 

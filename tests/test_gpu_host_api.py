@@ -154,6 +154,36 @@ def test_progressive_frame_keeps_the_accumulator_on_the_device(ctx, tmp_path):
     assert (rgba[..., 3] == 255).all()
 
 
+def test_a_cancelled_progressive_pass_is_counted_by_what_it_added(ctx, tmp_path):
+    """Renderer::cancelRender during ProgressiveFrame::add (the demo's window thread does that on every camera move,
+    PathTracerDemo.cpp:982): the sample batches the pass had finished are in the sums AND in the count, so the mean is the
+    frame of exactly that many samples, bit for bit.  MIPT_BATCH_PATHS makes the pass many batches long."""
+    import re
+    exe = os.path.join(LIB, "demo_headless")
+    if not os.path.exists(exe):
+        pytest.skip("demo_headless not built (make -C pathtracer_amd/host example)")
+    out = tmp_path / "cancelled.img"
+    w, h, spp = 256, 256, 2048
+    env = dict(os.environ, MIPT_BATCH_PATHS=str(64 * 64 * 32))   # slots exist only for the tiles that see the ball: a few samples per batch
+    r = subprocess.run([exe, str(w), str(h), str(spp), "8", "21", str(out), "1", "0", "cancel:25"], capture_output=True, text=True, timeout=200, env=env)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"pass (finished|cancelled): (\d+) samples per pixel counted, (\d+) passes", r.stdout)
+    assert m, r.stdout
+    done = int(m.group(2))
+    print(r.stdout.strip())
+    got = _load_image(out)
+    if m.group(1) == "finished":
+        assert done == spp                      # the cancel came too late on this machine: nothing to tell apart
+    else:
+        assert done < spp and int(m.group(3)) == (1 if done else 0)
+    if done == 0:
+        assert not got.any()
+        return
+    alg = api.HostAlgebra()
+    want, _ = ctx.render(ctx.upload(S.demo_scene(alg)), S.demo_camera(alg, w / h), w, h, 8, done, seed=21)
+    assert np.array_equal(got, want) and want.max() > 0
+
+
 def test_progressive_frame_resumes_from_a_checkpoint(ctx, tmp_path):
     """ProgressiveFrame::save / load (Image's raw format, src/Image.cpp:48-81, + the sample count and the renderer's
     position in its sample sequence): four passes of 3 spp, saved after the second and resumed by a new Renderer and a

@@ -95,9 +95,11 @@ def test_headline_view_converges_to_the_reference_renderers_image():
 
 def test_demo_view_at_1080p_against_the_cpu_restatement(oracle):
     """The headline frame's own view (not the close-up), 1920 x 1080, 16 spp on both sides: GPU against the CPU restatement of
-    the reference renderer (reference random numbers, two seeds) on the 256 x 256 crop around the ball.  Accepted as the
-    bench line's `rmse` object is: RMSE within 1.25 x the CPU's own seed-to-seed RMSE, the 8 x 8 box-filtered relative error
-    within 1.25 x of what two CPU seeds show, crop means within 2 %."""
+    the reference renderer (reference random numbers, two seeds) on the 256 x 256 crop around the ball.  At 16 samples
+    this is a noise-level check at the full frame size -- RMSE within 1.25 x the CPU's own seed-to-seed RMSE, the
+    box-filtered figure no larger than what two CPU seeds show (x 1.25), crop means within 2 % -- and says nothing about
+    bias below a few per cent; the bias bound (2 % box-filtered, 1 % of the mean) is
+    test_headline_view_converges_to_the_reference_renderers_image, above, against the reference's own renderer."""
     from oracle import orc
     z = np.load(FIXTURE, allow_pickle=False)
     alg = api.HostAlgebra()
