@@ -130,7 +130,7 @@ struct BounceCounters {
     uint32_t n_sdf;         // rays queued for the SDF march
     uint32_t sdf_head;      // (unused)
     uint32_t n_sdf_shade;   // hits queued for SDF shading
-    uint32_t extend_head[8];   // work-fetch cursors of extend, one per XCD
+    uint32_t unused_heads[8];
     uint32_t n_host_rays;   // rays gathered for one host object (reset per object)
     uint32_t n_host_shade;  // hits on host objects queued for shading on the host
     uint32_t n_carry;       // SDF marches this round's launch left unfinished for the next round's (may exceed the buffer: readers clamp)
@@ -138,6 +138,7 @@ struct BounceCounters {
     uint32_t pad2[12];
     // work-fetch cursors of the SDF march, each on a cache line of its own: atomics on one line are served one at a time
     uint32_t sdf_heads[kMarchCursors][32];
+    uint32_t extend_heads[8][32];   // work-fetch cursors of extend, one per XCD, likewise
 };
 
 // An SDF march that its launch handed on to the next round's launch instead of finishing it (k_sdf_march): everything

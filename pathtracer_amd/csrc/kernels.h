@@ -80,6 +80,8 @@ struct CullRects {
 constexpr int kMaxTraversalStack = 60;
 void launch_generate_extend(hipStream_t, const CameraRec&, const SceneDev&, const BatchParams&, const PathBuffers&, const CullRects&, int stack_need,
                             bool count = false);
+// generate alone: every visible path's camera ray into the arena, queue[0] and the bitmap (n_pix must be a multiple of 64); needs counters zeroed
+void launch_generate(hipStream_t, const CameraRec&, const BatchParams&, const PathBuffers&, const CullRects&);
 void launch_extend(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, int stack_need, bool count = false);
 // big-crater candidates of a crater ball: 12 floats per cell of the n^3 lattice cube at `base` (x-major)
 void launch_crater_cells(hipStream_t, const float off[3], const int base[3], int n, float* out);

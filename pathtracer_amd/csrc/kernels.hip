@@ -1001,14 +1001,19 @@ struct XcdCursor {
     uint32_t xcd, tried;  // cursor in use, number of cursors found exhausted
 };
 __device__ __forceinline__ bool xcd_cursor_empty(const XcdCursor& q) { return q.tried >= 8u && q.next >= q.end; }
-__device__ __forceinline__ bool xcd_cursor_take(XcdCursor& q, bool want, uint32_t* heads, uint32_t n, uint32_t& i) {
+__device__ __forceinline__ bool xcd_cursor_take(XcdCursor& q, bool want, uint32_t (*heads)[32], uint32_t n, uint32_t& i) {
     const unsigned long long fm = __ballot(want);
     if (!fm) return false;
     const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(fm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(fm), 0u));
     while (q.next >= q.end && q.tried < 8u) {
-        uint32_t c = 0;
-        if (__lane_id() == 0) c = atomicAdd(&heads[q.xcd], 1u);
-        c = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(c)));
+        // a plain look first: once a cursor is handed out, the thousands of waves that come by to find that out would
+        // otherwise queue up on its atomic (one address serves one atomic at a time), a fixed third of a millisecond
+        // at the end of every launch
+        uint32_t c = __hip_atomic_load(&heads[q.xcd][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((static_cast<unsigned long long>(c) * 8u + q.xcd) * 256u < n) {
+            if (__lane_id() == 0) c = atomicAdd(&heads[q.xcd][0], 1u);
+            c = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(c)));
+        }
         const unsigned long long begin = (static_cast<unsigned long long>(c) * 8u + q.xcd) * 256u;
         if (begin < n) {
             q.next = static_cast<uint32_t>(begin);
@@ -1122,6 +1127,48 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
 }
 
 // =============================================================================================
+// generate alone: the camera rays of every path of the batch go to the path arena and the live-path queue of bounce 0
+// names them all, in slot order; the closest-hit kernel of the later bounces (two rays per lane) then traces them like
+// any other queue.  For scenes of many analytic primitives that is faster than the fused kernel above, whose one ray
+// per lane in lockstep keeps half the lanes busy: the queue's neighbours are neighbouring pixels of one sample, as
+// coherent as rays get, and the 56 bytes a path costs in traffic are little beside a traversal of dozens of nodes.
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_generate(CameraRec cam, BatchParams bp, PathBuffers pb, CullRects cull) {
+    if (*pb.cancel_latch) return;
+    const uint32_t words_per_sample = bp.n_pix >> 6;   // n_pix is a multiple of 64 (whole 8 x 8 tiles)
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t traced = 0;
+    // a wave walks whole groups of 64 slots: 64 pixel ids of one sample, one word of the live-path bitmap
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < bp.n_slots; slot += stride) {
+        const uint32_t s = slot / bp.n_pix, id = slot - s * bp.n_pix;
+        uint32_t x = 0, y = 0;
+        const bool in_image = pixel_of(bp, id, x, y);
+        bool visible = false;
+        if (in_image)
+            for (int k = 0; k < cull.n; ++k)
+                visible = visible || (static_cast<int>(x) >= cull.r[k][0] && static_cast<int>(y) >= cull.r[k][1] && static_cast<int>(x) <= cull.r[k][2] &&
+                                      static_cast<int>(y) <= cull.r[k][3]);
+        // The queue names every slot of the batch, in order (no compaction: no counter to contend for).  A slot without a
+        // ray -- tile padding, a pixel from which nothing can be seen -- gets the null direction, which the closest-hit
+        // kernels answer with a miss without tracing anything.
+        f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
+        if (visible) {
+            camera_ray(cam, bp, y * bp.width + x, bp.first_sample + s, static_cast<float>(x) / static_cast<float>(bp.width - 1),
+                       static_cast<float>(y) / static_cast<float>(bp.height - 1), o, d);
+            pb.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            ++traced;
+        }
+        pb.ray_o[slot] = st4(o);
+        pb.ray_d[slot] = st4(d);
+        pb.queue[0][slot] = slot;
+        const unsigned long long vis = __ballot(visible);
+        if ((threadIdx.x & 63u) == 0u) pb.live_bits[static_cast<size_t>(s) * words_per_sample + (id >> 6)] = vis;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) pb.counters[0].n_live = bp.n_slots;
+    wave_add_total(&pb.totals->primary_traced, traced);
+}
+
+// =============================================================================================
 // extend: closest hit for the rays of the live-path queue (bounces after the first, or rays loaded
 // from the host).  Persistent waves; a lane that finishes its ray takes the next one from the queue.
 // =============================================================================================
@@ -1139,7 +1186,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
     // queue up on the cursors to learn that nothing is left
     if (static_cast<unsigned long long>(blockIdx.x) * 256u >= n) return;
     const uint32_t* queue = pb.queue[bounce & 1];
-    uint32_t* heads = pb.counters[bounce].extend_head;
+    uint32_t (*heads)[32] = pb.counters[bounce].extend_heads;
     int* stack = s_stack + threadIdx.x;
     f3 box_lo = mk3(0, 0, 0), box_hi = mk3(0, 0, 0);
     if (sc.n_sdf) {
@@ -1156,7 +1203,9 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
         uint32_t i = 0;
         if (xcd_cursor_take(cursor, !t.busy && !xcd_cursor_empty(cursor), heads, n, i)) {
             const uint32_t slot = queue[i];
-            trav_begin(t, ld3(pb.ray_o[slot]), ld3(pb.ray_d[slot]), slot, sc.nodes != nullptr);
+            const f3 d = ld3(pb.ray_d[slot]);
+            if (d.x == 0.0f && d.y == 0.0f && d.z == 0.0f) pb.hit_key[slot] = kMissKey;   // a slot without a ray (k_generate)
+            else trav_begin(t, ld3(pb.ray_o[slot]), d, slot, sc.nodes != nullptr);
         }
         if (!__ballot(t.busy)) {
             if (xcd_cursor_empty(cursor)) break;
@@ -1195,7 +1244,7 @@ __global__ void __launch_bounds__(256) k_extend_pair(SceneDev sc, BatchParams bp
     const uint32_t n = pb.counters[bounce].n_live;
     if (static_cast<unsigned long long>(blockIdx.x) * 256u >= n) return;
     const uint32_t* queue = pb.queue[bounce & 1];
-    uint32_t* heads = pb.counters[bounce].extend_head;
+    uint32_t (*heads)[32] = pb.counters[bounce].extend_heads;
     int* col = s_stack + threadIdx.x;
     const int rows = bp.pair_rows ? min(static_cast<int>(bp.pair_rows), S) : S;
     f3 box_lo = mk3(0, 0, 0), box_hi = mk3(0, 0, 0);
@@ -1227,7 +1276,9 @@ __global__ void __launch_bounds__(256) k_extend_pair(SceneDev sc, BatchParams bp
         uint32_t i = 0;
         if (xcd_cursor_take(cursor, !pair_busy(t) && !xcd_cursor_empty(cursor), heads, n, i)) {
             const uint32_t slot = queue[i];
-            pair_begin(t, ld3(pb.ray_o[slot]), ld3(pb.ray_d[slot]), slot, sc.nodes != nullptr);
+            const f3 d = ld3(pb.ray_d[slot]);
+            if (d.x == 0.0f && d.y == 0.0f && d.z == 0.0f) pb.hit_key[slot] = kMissKey;   // a slot without a ray (k_generate)
+            else pair_begin(t, ld3(pb.ray_o[slot]), d, slot, sc.nodes != nullptr);
         }
     };
     for (;;) {
@@ -2254,6 +2305,10 @@ void launch_generate_extend(hipStream_t st, const CameraRec& cam, const SceneDev
     else if (stack_need <= 48) MIPT_LAUNCH_GE(48, 128);
     else MIPT_LAUNCH_GE(60, 128);
 #undef MIPT_LAUNCH_GE
+}
+
+void launch_generate(hipStream_t st, const CameraRec& cam, const BatchParams& bp, const PathBuffers& pb, const CullRects& cull) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(bp.n_slots, 256u * 16u)), dim3(256), 0, st, cam, bp, pb, cull);
 }
 
 void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce, int stack_need, bool count) {

@@ -53,7 +53,8 @@ def test_culled_traversal_equals_the_scan_over_every_object(n, extent, radius_sc
     for name, env in (("two rays per lane", {"MIPT_NO_CULL": "0"}), ("one ray per lane", {"MIPT_NO_CULL": "0", "MIPT_PAIR_QUORUM": "0"}),
                       ("two rays per lane, leaf steps at once", {"MIPT_NO_CULL": "0", "MIPT_PAIR_QUORUM": "1", "MIPT_PAIR_KEEP": "128"}),
                       ("two rays per lane, late leaf steps", {"MIPT_NO_CULL": "0", "MIPT_PAIR_QUORUM": "64", "MIPT_PAIR_KEEP": "16"}),
-                      ("two rays per lane, stack entries without distances", {"MIPT_NO_CULL": "0", "MIPT_PAIR_PLAIN": "1"})):
+                      ("two rays per lane, stack entries without distances", {"MIPT_NO_CULL": "0", "MIPT_PAIR_PLAIN": "1"}),
+                      ("camera rays written out and traced by the two-rays-per-lane kernel", {"MIPT_NO_CULL": "0", "MIPT_SPLIT_PRIMARY": "1"})):
         img, st = _render(flat, cam, w, spp, bounces, env)
         assert st["rays"] == st_scan["rays"], (name, st["rays"], st_scan["rays"])
         assert np.array_equal(img, scan), name
@@ -95,10 +96,12 @@ def test_small_far_objects_the_one_deviation_of_a_culling_traversal_stays_at_its
     cam = S.random_scene_camera(alg, 1.0)
     w, spp, bounces = 448, 8, 8
     scan, st_scan = _render(flat, cam, w, spp, bounces, {"MIPT_NO_CULL": "1"})
-    img, st = _render(flat, cam, w, spp, bounces, {"MIPT_NO_CULL": "0"})
-    differing = int((img != scan).any(axis=2).sum())
-    print(f"20,000 small objects: {st_scan['rays']} rays scanned over every object, culled traversal {st['rays']} rays "
-          f"({abs(st['rays'] - st_scan['rays'])} apart), {differing} of {w * w} pixels differ")
     assert st_scan["rays"] > 1.2 * st_scan["paths"]
-    assert abs(st["rays"] - st_scan["rays"]) <= max(2, 1e-5 * st_scan["rays"])
-    assert differing <= 4
+    # (camera rays through the fused kernel, and through the two-rays-per-lane kernel as frames of 50,000 objects and more send them)
+    for split in ("0", "1"):
+        img, st = _render(flat, cam, w, spp, bounces, {"MIPT_NO_CULL": "0", "MIPT_SPLIT_PRIMARY": split})
+        differing = int((img != scan).any(axis=2).sum())
+        print(f"20,000 small objects: {st_scan['rays']} rays scanned over every object, culled traversal (split primary {split}) {st['rays']} rays "
+              f"({abs(st['rays'] - st_scan['rays'])} apart), {differing} of {w * w} pixels differ")
+        assert abs(st["rays"] - st_scan["rays"]) <= max(2, 1e-5 * st_scan["rays"])
+        assert differing <= 4
