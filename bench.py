@@ -303,7 +303,7 @@ def main():
                 # is the share of the pipes' lane-slots that did work -- the executed-work roofline fraction of this kernel.
                 march_s = stage_ms["sdf_march"] / a.steps * 1e-3
                 issue = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (march_s * 2.4e9 * 1024.0)
-                lanes = sq["SQ_THREAD_CYCLES_VALU"] / max(1.0, sq["SQ_ACTIVE_INST_VALU"]) / 4.0
+                lanes = sq["SQ_THREAD_CYCLES_VALU"] / max(1.0, sq["SQ_ACTIVE_INST_VALU"])
                 executed = {"valu_issue_frac": issue, "active_lanes": lanes, "lane_slot_frac": issue * lanes / 64.0,
                             "valu_wave_insts_per_frame": sq["SQ_INSTS_VALU"], "salu_wave_insts_per_frame": sq["SQ_INSTS_SALU"],
                             "valu_insts_per_near_eval": sq["SQ_INSTS_VALU"] / max(1.0, agg["sdf_near_evals"] / a.steps),
@@ -337,7 +337,8 @@ def main():
                 ("random1m", 3840, 2160, 32): "random1m_4k_32spp"}.get((a.scene, W, H, a.spp))
         if prof and world == 1:
             path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_fetch_{prof}.csv")
-            ext, gen = pmc_rows(path, "k_extend"), pmc_rows(path, "k_generate_extend<")   # the first rows are the plain (not the counting) builds
+            # (the first rows are the plain, not the counting, builds; camera rays come from the fused kernel or, written out by k_generate, through k_extend_pair)
+            ext, gen = pmc_rows(path, "k_extend"), pmc_rows(path, "k_generate_extend<") or pmc_rows(path, "k_generate")
             if ext and gen:
                 traffic = 2.0 * (ext["FETCH_SIZE"] + gen["FETCH_SIZE"]) * 1024.0 / max(1.0, ext["dispatches"] + gen["dispatches"])
                 traffic_source = f"profiles/{PROFILE_ROUND}_pmc_fetch_{prof}.csv: 2 x FETCH_SIZE KB per launch (reads that go past L2; wide reads corrected x2)"
