@@ -58,6 +58,7 @@ struct mipt_ctx {
     // MIPT_CARRY_LAG (0: off), MIPT_CARRY_AFTER: SDF marches still running when a launch's queue is handed out go to the next
     // round's launch (BatchParams::carry_max_lag, carry_after)
     uint32_t carry_lag = 4, carry_after = 32;
+    bool no_few = false;            // MIPT_NO_FEW=1 (test aid): the closest-hit kernel for scenes of a handful of primitives is not used
     int split_primary = -1;         // MIPT_SPLIT_PRIMARY: 1 = camera rays are written out and traced by the later bounces' kernel, 0 = by the fused kernel, unset = by scene
     uint32_t carry_cap = 0;         // records in each of the two hand-over buffers of the arena
     int min_stack = 0;   // MIPT_MIN_STACK: the traversal kernels are picked as if every tree needed at least this many stack entries (a test aid)
@@ -625,7 +626,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
             break;
         }
         const uint32_t now = std::min(per_batch, st->spp - done);
-        BatchParams bp;
+        BatchParams bp{};
         bp.n_pix = static_cast<uint32_t>(n_pix);
         bp.n_slots = static_cast<uint32_t>(n_pix * now);
         bp.width = st->width;
@@ -635,6 +636,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.first_sample = st->first_sample + done;
         bp.flags = (st->flags & static_cast<uint32_t>(MIPT_FLAG_NO_JITTER)) | (c->full_march ? kFlagFullMarch : 0u);
         bp.lane_threshold = c->lane_threshold;
+    bp.no_few = c->no_few ? 1u : 0u;
         // marches are handed on only where nothing synchronises with the host inside a batch
         bp.carry_max_lag = (sc->n_sdf && sc->host_prims.empty()) ? std::min<uint32_t>(c->carry_lag, kCounterRows - 1 - st->bounces) : 0u;
         bp.carry_after = c->carry_after;
@@ -765,6 +767,7 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
     }
     if (const char* e = std::getenv("MIPT_FULL_MARCH")) c->full_march = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_CARRY_LAG")) c->carry_lag = static_cast<uint32_t>(std::min(long(kMaxCarryLag), std::max(0L, std::atol(e))));
+    if (const char* e = std::getenv("MIPT_NO_FEW")) c->no_few = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_SPLIT_PRIMARY")) c->split_primary = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("MIPT_CARRY_AFTER")) c->carry_after = static_cast<uint32_t>(std::min(100000L, std::max(0L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_DEVICE_BVH")) c->device_bvh = std::atoi(e) != 0;
@@ -1368,6 +1371,7 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     bp.height = height;
     bp.flags = MIPT_FLAG_NO_JITTER | (c->full_march ? kFlagFullMarch : 0u);
     bp.lane_threshold = c->lane_threshold;
+    bp.no_few = c->no_few ? 1u : 0u;
     bp.trav_quorum = c->trav_quorum;
     bp.trav_quorum_primary = c->trav_quorum_primary;
     bp.trav_keep = c->trav_keep;
@@ -1426,6 +1430,7 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     bp.width = n;
     bp.height = 1;
     bp.lane_threshold = c->lane_threshold;
+    bp.no_few = c->no_few ? 1u : 0u;
     bp.trav_quorum = c->trav_quorum;
     bp.trav_quorum_primary = c->trav_quorum_primary;
     bp.trav_keep = c->trav_keep;

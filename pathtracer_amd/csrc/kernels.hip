@@ -1233,6 +1233,63 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
     }
 }
 
+// The same for scenes of a handful of primitives (the demo scene: a crater ball and a slab): no tree, no persistent
+// waves, no wave state machine -- a thread takes a ray, tests every analytic primitive in index order and keeps the
+// closest hit, ties to the lower index (ObjectTree::Tree::hit, src/ObjectTree.cpp:22-88, literally).  The machinery
+// above costs such rays ten times what their memory traffic does.
+__global__ void __launch_bounds__(256) k_extend_few(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t round) {
+    if (*pb.cancel_latch) return;
+    constexpr uint32_t kCap = 1024;
+    __shared__ uint32_t s_pend[4 * kCap];
+    __shared__ uint32_t s_meet[8];
+    PendingQueue to_sdf{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u};
+    const uint32_t n = pb.counters[round].n_live;
+    const uint32_t* queue = pb.queue[round & 1];
+    f3 box_lo = mk3(0, 0, 0), box_hi = mk3(0, 0, 0);
+    if (sc.n_sdf) {
+        box_lo = mk3(sc.sdf_boxes[0].lo[0], sc.sdf_boxes[0].lo[1], sc.sdf_boxes[0].lo[2]);
+        box_hi = mk3(sc.sdf_boxes[0].hi[0], sc.sdf_boxes[0].hi[1], sc.sdf_boxes[0].hi[2]);
+    }
+    uint32_t n_sdf_rays = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (n + stride - 1) / stride;   // every lane of a wave runs every round: the appends are wave-wide
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool wants_sdf = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = queue[i];
+            const f3 o = ld3(pb.ray_o[slot]), d = ld3(pb.ray_d[slot]);
+            unsigned long long best = kMissKey;
+            f3 best_pos = mk3(0.0f, 0.0f, 0.0f);
+            float limit = 3.0e38f;
+            const bool has_ray = !(d.x == 0.0f && d.y == 0.0f && d.z == 0.0f);   // (the null direction: a slot without a ray, k_generate)
+            if (has_ray) {
+                for (uint32_t prim = 0; prim < sc.n_prims; ++prim) {
+                    if (sc.prims[prim].kind > 2u) continue;
+                    f3 w;
+                    float th;
+                    if (hit_analytic_from(sc.prims, sc.tri_c, prim, o, d, w, th)) {
+                        const unsigned long long key = make_key(th, prim);
+                        if (key < best) {
+                            best = key;
+                            best_pos = w;
+                            limit = fmaxf(th, 0.0f) * (1.0f / norm_sq(d)) * 1.00001f + 1e-6f;
+                        }
+                    }
+                }
+                wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, o, d, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), limit, !(bp.flags & kFlagFullMarch));
+            }
+            pb.hit_key[slot] = best;
+            pb.hit_pos[slot] = st4(best_pos);
+        }
+        pending_push(to_sdf, wants_sdf, slot, &pb.counters[round].n_sdf, pb.sdf_queue);
+        n_sdf_rays += wants_sdf ? 1u : 0u;
+    }
+    pending_flush_block(to_sdf, &pb.counters[round].n_sdf, pb.sdf_queue, s_meet);
+    wave_add_total(&pb.totals->sdf_rays, n_sdf_rays);
+}
+
 // The same with two rays per lane (trav_run_pair): the lane's column of S stack entries is shared by both.
 template <int S, bool COUNT, bool DIST>
 __global__ void __launch_bounds__(256) k_extend_pair(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t bounce) {
@@ -2327,6 +2384,10 @@ void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, co
     } while (0)
     // stack entries that carry their entry distance: the tree's links must fit 20 bits (the counting build is only
     // instantiated for such trees; larger ones are counted by the one-ray kernels)
+    if (sc.n_prims <= 8u && !count && !bp.no_few) {   // a handful of primitives: tested one after the other, no tree
+        hipLaunchKernelGGL(k_extend_few, dim3(grid_for(bp.n_slots, 256u * 8u)), dim3(256), 0, st, sc, bp, pb, bounce);
+        return;
+    }
     const bool dist = sc.n_prims <= (1u << 20) && sc.n_nodes <= (1u << 20) && !bp.pair_plain_entries;
     if (bp.trav_quorum_pair && stack_need > 8 && (dist || !count)) {
         // two rays per lane: one column of S entries for both (S >= the tree's need + 3: the second ray asks for three free rows before every visit, and must find them when it is alone)

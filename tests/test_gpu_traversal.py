@@ -105,3 +105,25 @@ def test_small_far_objects_the_one_deviation_of_a_culling_traversal_stays_at_its
               f"({abs(st['rays'] - st_scan['rays'])} apart), {differing} of {w * w} pixels differ")
         assert abs(st["rays"] - st_scan["rays"]) <= max(2, 1e-5 * st_scan["rays"])
         assert differing <= 4
+
+
+def test_scenes_of_a_handful_of_primitives_need_no_tree():
+    """Up to eight primitives are tested one after the other per ray (k_extend_few) instead of through the tree and the
+    wave state machine; MIPT_NO_FEW=1 sends the same frames through the tree.  A crater ball with its slab, and six
+    analytic primitives of all three kinds with glass and a mirror among them: identical frames and ray counts."""
+    alg = api.HostAlgebra()
+    demo, demo_cam = S.demo_scene(alg), S.demo_camera(alg, 1.0)
+    b = S.SceneBuilder(alg)
+    matte = S.material(diffuse=1.0, specular=0.0, albedo=(0.7, 0.6, 0.5))
+    b.box((4.0, 0.1, 4.0), S.material(diffuse=1.0, specular=0.0, emitted=(3.0, 3.0, 2.5)), S.translation(0.0, -3.0, 0.0))
+    b.sphere(1.0, S.material(diffuse=0.05, specular=0.95, sharpness=0.95), S.translation(-1.2, 0.0, 0.0))
+    b.sphere(0.8, S.material(diffuse=0.05, specular=0.05, transmittance=0.9, ior=1.55), S.translation(1.1, 0.2, -0.5))
+    b.box((0.6, 0.9, 0.4), matte, alg.affine_mul(S.translation(0.2, 0.9, 1.5), S.linear_to_affine(alg.rotation("y", 0.6))))
+    b.triangle((-3.0, 2.5, 3.0), (3.0, 2.5, 3.0), (0.0, -2.0, 3.5), matte)
+    b.triangle((-3.0, -1.0, -1.0), (-2.5, 2.0, 2.0), (-3.5, 2.0, -2.0), matte)
+    small, small_cam = b.build(), S.camera(S.translation(0.0, 0.0, -9.0), aspect=1.0, fov=25.0, focal=9.0, blur=0.05)
+    for flat, cam, w, spp, bounces in ((demo, demo_cam, 256, 8, 8), (small, small_cam, 192, 16, 10)):
+        tree, st_tree = _render(flat, cam, w, spp, bounces, {"MIPT_NO_FEW": "1"})
+        few, st_few = _render(flat, cam, w, spp, bounces, {"MIPT_NO_FEW": "0"})
+        assert st_tree["rays"] == st_few["rays"] and st_few["rays"] > st_few["paths"]
+        assert np.array_equal(tree, few) and few.max() > 0

@@ -1,6 +1,6 @@
 """Times the demo frame under the march's scheduling switches and checks that the frame and the work counters do not
 depend on them.  Each configuration is a set of NAME=VALUE pairs (MIPT_CARRY_LAG, MIPT_CARRY_AFTER,
-MIPT_LANE_THRESHOLD); the first one is the base the others are compared with.
+MIPT_LANE_THRESHOLD, MIPT_NO_FEW); the first one is the base the others are compared with.
 
     python tools/sweep_carry.py SPP[,SPP...] "MIPT_CARRY_LAG=0" "MIPT_CARRY_LAG=4 MIPT_CARRY_AFTER=32" ...   (on the GPU box)
 """
@@ -14,7 +14,7 @@ from pathtracer_amd import api, scene as S   # noqa: E402
 
 W, H, BOUNCES = 1920, 1080, 8
 SAME = ("paths", "rays", "sdf_rays", "sdf_shades", "sdf_far_evals", "sdf_near_evals", "sdf_noise_calls", "shade_evals")
-SWITCHES = ("MIPT_CARRY_LAG", "MIPT_CARRY_AFTER", "MIPT_LANE_THRESHOLD")
+SWITCHES = ("MIPT_CARRY_LAG", "MIPT_CARRY_AFTER", "MIPT_LANE_THRESHOLD", "MIPT_NO_FEW")
 
 
 def run(env, spp, frames=4):
