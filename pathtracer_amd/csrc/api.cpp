@@ -58,6 +58,7 @@ struct mipt_ctx {
     // MIPT_CARRY_LAG (0: off), MIPT_CARRY_AFTER: SDF marches still running when a launch's queue is handed out go to the next
     // round's launch (BatchParams::carry_max_lag, carry_after)
     uint32_t carry_lag = 4, carry_after = 32;
+    size_t minor_table_balls = 64;  // MIPT_CELL_TABLE_BALLS: scenes with up to this many crater balls get the small / tiny crater cell tables (0: none)
     bool no_few = false;            // MIPT_NO_FEW=1 (test aid): the closest-hit kernel for scenes of a handful of primitives is not used
     int split_primary = -1;         // MIPT_SPLIT_PRIMARY: 1 = camera rays are written out and traced by the later bounces' kernel, 0 = by the fused kernel, unset = by scene
     uint32_t carry_cap = 0;         // records in each of the two hand-over buffers of the arena
@@ -89,6 +90,7 @@ struct mipt_scene {
     void* d_oct = nullptr;
     void* d_craters = nullptr;
     void* d_crater_masks = nullptr;
+    void* d_minor_cells = nullptr;   // small / tiny crater cell tables of the crater balls
     uint32_t n_nodes = 0, n_analytic = 0, n_sdf = 0;
     int depth = 0;        // levels of the two-child tree the builders made
     int stack_need = 0;   // traversal stack entries the four-child tree can need
@@ -768,6 +770,7 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
     if (const char* e = std::getenv("MIPT_FULL_MARCH")) c->full_march = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_CARRY_LAG")) c->carry_lag = static_cast<uint32_t>(std::min(long(kMaxCarryLag), std::max(0L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_NO_FEW")) c->no_few = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_CELL_TABLE_BALLS")) c->minor_table_balls = static_cast<size_t>(std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("MIPT_SPLIT_PRIMARY")) c->split_primary = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("MIPT_CARRY_AFTER")) c->carry_after = static_cast<uint32_t>(std::min(100000L, std::max(0L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_DEVICE_BVH")) c->device_bvh = std::atoi(e) != 0;
@@ -1006,6 +1009,7 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
     // arithmetic the kernels use; the cells that pass are kept in lattice order.
     std::vector<float> craters;
     std::vector<unsigned long long> crater_masks;
+    std::vector<float> ball_offsets;   // CraterBallObject::offset of every ball, by ordinal
     if (any_sdf) {
         constexpr int kCube = 9;
         constexpr size_t kCells = size_t(kCube) * kCube * kCube;
@@ -1059,6 +1063,7 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
                         }
             }
             const uint32_t packed = count | (ordinal << 8);
+            ball_offsets.insert(ball_offsets.end(), r.p, r.p + 3);
             std::memcpy(&r.q[0], &first, 4);
             std::memcpy(&r.q[1], &packed, 4);
         }
@@ -1129,6 +1134,17 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
         if (e == hipSuccess) e = upload(&s->d_oct, oct, sizeof(oct));
         if (e == hipSuccess) e = upload(&s->d_craters, craters.data(), craters.size() * sizeof(float));
         if (e == hipSuccess) e = upload(&s->d_crater_masks, crater_masks.data(), crater_masks.size() * sizeof(unsigned long long));
+        // The small and tiny craters' cells of every ball, in the order of the balls' ordinals (the order of `sdf`).  30 MB
+        // a ball: scenes with more balls than kMinorTableBalls go without, and the evaluators compute the cells.
+        if (e == hipSuccess && !ball_offsets.empty() && ball_offsets.size() <= 3 * c->minor_table_balls) {
+            const size_t per_ball = minor_cells_bytes_per_ball();
+            e = hipMalloc(&s->d_minor_cells, per_ball * (ball_offsets.size() / 3));
+            for (size_t b = 0; e == hipSuccess && b < ball_offsets.size() / 3; ++b) {
+                launch_minor_cells(c->stream, &ball_offsets[3 * b], static_cast<char*>(s->d_minor_cells) + per_ball * b);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
     }
     if (e != hipSuccess) {
         c->last_hip = static_cast<int>(e);
@@ -1146,6 +1162,7 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
     s->dev.plain_sdf = any_plain ? 1u : 0u;
     s->dev.craters = static_cast<const float*>(s->d_craters);
     s->dev.crater_masks = static_cast<const unsigned long long*>(s->d_crater_masks);
+    s->dev.minor_cells = s->d_minor_cells;
     s->dev.n_sdf = static_cast<uint32_t>(sdf.size());
     s->dev.n_prims = n;
     s->dev.n_nodes = static_cast<uint32_t>(qnodes.size());
@@ -1208,7 +1225,7 @@ void mipt_scene_free(mipt_scene* s) {
     if (!s) return;
     // hipFree waits for work that still uses the memory; the context may already be gone
     (void)hipSetDevice(s->device);
-    for (void* p : {s->d_prims, s->d_tri, s->d_mats, s->d_nodes, s->d_leaf_boxes, s->d_sdf, s->d_oct, s->d_craters, s->d_crater_masks, s->d_host_boxes})
+    for (void* p : {s->d_prims, s->d_tri, s->d_mats, s->d_nodes, s->d_leaf_boxes, s->d_sdf, s->d_oct, s->d_craters, s->d_crater_masks, s->d_minor_cells, s->d_host_boxes})
         if (p) (void)hipFree(p);
     delete s;
 }

@@ -246,6 +246,53 @@ __device__ __forceinline__ float near_total(float s, int big_fix, float crater_s
     return ((((s + crater) + tiny) + from_fix(fallout)) + 0.01f * nf1) + 0.4f * nf2;
 }
 
+// The small and tiny craters' lattice cells do not depend on the query either: a cell's hash, its jittered point and
+// that point's projection onto the sphere of radius `scale` about the ball's offset follow from the cell and the offset.
+// A query (offset + scale u, |u| = 1) falls into cells floor(offset) - scale - 1 .. floor(offset) + scale + 1 and looks
+// at each cell and its upper neighbour, so a cube of 2 scale + 4 cells per axis about floor(offset) - scale - 1 covers
+// all of them: 24^3 cells at scale 10, 124^3 at scale 60, one float4 per cell -- {on_sphere.xyz, hash bits} for a cell
+// that passes the shell test, {+inf, 0, 0, hash bits} for one that does not (its distance from any query is then +inf,
+// which fails every later test the way `pass` did).  Made once per ball by k_minor_cells with the very functions the
+// evaluators use, so a value read from the table is the value computed on the spot, bit for bit.
+constexpr int kSmallCube = 24, kTinyCube = 124;
+constexpr uint32_t kSmallCells = kSmallCube * kSmallCube * kSmallCube, kTinyCells = kTinyCube * kTinyCube * kTinyCube;
+constexpr uint32_t kMinorCellsPerBall = kSmallCells + kTinyCells;   // float4s per ball: the small craters' cube, then the tiny ones'
+__global__ void __launch_bounds__(256) k_minor_cells(float ox, float oy, float oz, float4* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kMinorCellsPerBall) return;
+    const bool tiny = i >= kSmallCells;
+    const uint32_t j = tiny ? i - kSmallCells : i;
+    const uint32_t n = tiny ? kTinyCube : kSmallCube;
+    const float scale = tiny ? 60.0f : 10.0f;
+    const f3 off = mk3(ox, oy, oz);
+    const f3 g = mk3((floorf(ox) - (scale + 1.0f)) + static_cast<float>(j / (n * n)), (floorf(oy) - (scale + 1.0f)) + static_cast<float>((j / n) % n),
+                     (floorf(oz) - (scale + 1.0f)) + static_cast<float>(j % n));
+    const uint32_t h2 = cell_hash_mix(cell_hash_seed(g));
+    const f3 pt2 = jitter_unit(mk3(g.x - 0.5f, g.y - 0.5f, g.z - 0.5f), h2);
+    f3 on2;
+    const bool pass = project_cell(pt2, off, scale, on2);
+    out[i] = pass ? make_float4(on2.x, on2.y, on2.z, __uint_as_float(h2)) : make_float4(__uint_as_float(0x7f800000u), 0.0f, 0.0f, __uint_as_float(h2));
+}
+// Index, within a ball's cube of `n` cells per axis that starts at floor(offset) - first, of the cell a query falls into.
+__device__ __forceinline__ uint32_t minor_cell_index(f3 q2, f3 off, float first, int n) {
+    const int ix = static_cast<int>(floorf(q2.x) - (floorf(off.x) - first)), iy = static_cast<int>(floorf(q2.y) - (floorf(off.y) - first)),
+              iz = static_cast<int>(floorf(q2.z) - (floorf(off.z) - first));
+    const int hi = n - 2;   // (a query cannot leave the cube and has its upper neighbour inside: the clamp only keeps a wrong address impossible)
+    return static_cast<uint32_t>((min(max(ix, 0), hi) * n + min(max(iy, 0), hi)) * n + min(max(iz, 0), hi));
+}
+// The same cell as minor_cell() from its table entry.
+__device__ __forceinline__ MinorCell minor_cell_from(f3 q2, float4 rec, bool tiny) {
+    MinorCell m;
+    const uint32_t h2 = __float_as_uint(rec.w);
+    m.pass = true;   // a cell that does not pass lies at +inf
+    const float t2 = static_cast<float>(h2 & 0xffffu) * (1.0f / 65535.0f);
+    m.age = h2 >> 16;
+    const float d2 = __builtin_amdgcn_sqrtf(fnorm2(q2 - mk3(rec.x, rec.y, rec.z)));
+    m.size = tiny ? fmaf(0.35f, t2, 0.02f) : fmaf(0.35f * t2, t2, 0.05f);
+    m.c50 = 50.0f * (d2 - m.size);
+    return m;
+}
+
 // What each lane contributes to the cooperative parts of an evaluation.
 struct CoopLane {
     float si, sj, sk;   // lanes 0-7 / 8-15 of a row: cell of the 2^3 small / tiny-crater neighbourhood (0..1)
@@ -511,7 +558,7 @@ __device__ __forceinline__ uint32_t crater_cell_index(f3 query, f3 off) {
 // crater table (lane c holds crater c in t0..t2) with its cell masks is the same for all of them.
 // Returns false for a lane whose point has more fallout deposits than a lane can hold; its `out` is
 // then not written.
-__device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, const unsigned long long* cell_masks, const CoopLane& cl, float* lds, bool active,
+__device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, const unsigned long long* cell_masks, const float4* minor, const CoopLane& cl, float* lds, bool active,
                                           f3 pos, f3 off, float s, uint32_t lane, float& out, uint32_t& noise_calls) {
     float* rx = lds;
     float* ry = lds + kRing;
@@ -584,39 +631,13 @@ __device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, const
         }
     }
 
-    // ---- small and tiny craters, cell by cell in the reference's order --------------------------
+    // ---- small and tiny craters, cell by cell in the reference's order; remaining noise() calls; fallout -------------
+    // With the ball's cell tables, the eight small-crater entries are asked for before the fallout of the big craters is
+    // summed and each tiny-crater entry as soon as the small-crater entry whose registers it takes has been used, so
+    // that the answers are there when they are needed.
     float least_c50 = kNoSmallCrater, tiny = 0.0f;
-    if (active) {
-#pragma unroll 1
-        for (int pass_no = 0; pass_no < 2; ++pass_no) {
-            const bool is_tiny = pass_no != 0;
-            const float scale = is_tiny ? 60.0f : 10.0f;
-            const f3 q2 = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
-            const f3 f2 = mk3(floorf(q2.x), floorf(q2.y), floorf(q2.z));
-            const uint32_t seed0 = cell_hash_seed(f2);   // the neighbours' seeds differ from it by wave-uniform constants
-#pragma unroll 8
-            for (int cell = 0; cell < 8; ++cell) {
-                const int dx = cell >> 2, dy = (cell >> 1) & 1, dz = cell & 1;
-                const uint32_t seed = seed0 + static_cast<uint32_t>(dx * kHashX + dy * kHashY + dz * kHashZ);
-                const f3 gm = mk3(f2.x + (dx ? 0.5f : -0.5f), f2.y + (dy ? 0.5f : -0.5f), f2.z + (dz ? 0.5f : -0.5f));
-                const MinorCell mc = minor_cell(q2, seed, gm, off, scale, is_tiny);
-                if (!is_tiny) {
-                    if (mc.pass && mc.c50 < 0.0f && mc.age <= min_age) {
-                        least_c50 = fminf(least_c50, mc.c50);
-                        min_age = mc.age;
-                    }
-                } else if (mc.pass && mc.age <= min_age && mc.c50 < kTinyReach) {
-                    tiny = fmaxf(tiny, tiny_term(mc));
-                }
-            }
-        }
-    }
-    const float crater_small = small_total(least_c50);
-
-    // ---- remaining noise() calls, then fallout and the final sum ----------------------------------
-    noise_ring_rounds(cl, lds, lane, done, staged, true);
-    if (active && !overflow) {
-        int fallout = 0;
+    int fallout = 0;
+    auto sum_fallout = [&]() {
         float4 e = *reinterpret_cast<const float4*>(lds + kCol + 4u * lane);
         for (uint32_t j = 0; j < n_dep; ++j) {
             const uint32_t jn = j + 1u < static_cast<uint32_t>(kLaneDeposits) ? j + 1u : j;
@@ -624,8 +645,65 @@ __device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, const
             fallout += fallout_fix(e.x, e.y, e.z, e.w);
             e = en;
         }
+    };
+    if (minor) {
+        noise_ring_rounds(cl, lds, lane, done, staged, true);
+        if (active) {
+            const f3 q_small = mk3(fmaf(u.x, 10.0f, off.x), fmaf(u.y, 10.0f, off.y), fmaf(u.z, 10.0f, off.z));
+            const f3 q_tiny = mk3(fmaf(u.x, 60.0f, off.x), fmaf(u.y, 60.0f, off.y), fmaf(u.z, 60.0f, off.z));
+            const float4* at_small = minor + minor_cell_index(q_small, off, 11.0f, kSmallCube);
+            const float4* at_tiny = minor + kSmallCells + minor_cell_index(q_tiny, off, 61.0f, kTinyCube);
+            float4 rec[8];
+#pragma unroll
+            for (int cell = 0; cell < 8; ++cell) rec[cell] = at_small[((cell >> 2) * kSmallCube + ((cell >> 1) & 1)) * kSmallCube + (cell & 1)];
+            sum_fallout();
+#pragma unroll
+            for (int cell = 0; cell < 8; ++cell) {
+                const MinorCell mc = minor_cell_from(q_small, rec[cell], false);
+                rec[cell] = at_tiny[((cell >> 2) * kTinyCube + ((cell >> 1) & 1)) * kTinyCube + (cell & 1)];
+                if (mc.c50 < 0.0f && mc.age <= min_age) {
+                    least_c50 = fminf(least_c50, mc.c50);
+                    min_age = mc.age;
+                }
+            }
+#pragma unroll
+            for (int cell = 0; cell < 8; ++cell) {
+                const MinorCell mc = minor_cell_from(q_tiny, rec[cell], true);
+                if (mc.age <= min_age && mc.c50 < kTinyReach) tiny = fmaxf(tiny, tiny_term(mc));
+            }
+        }
+    } else {
+        if (active) {
+#pragma unroll 1
+            for (int pass_no = 0; pass_no < 2; ++pass_no) {
+                const bool is_tiny = pass_no != 0;
+                const float scale = is_tiny ? 60.0f : 10.0f;
+                const f3 q2 = mk3(fmaf(u.x, scale, off.x), fmaf(u.y, scale, off.y), fmaf(u.z, scale, off.z));
+                const f3 f2 = mk3(floorf(q2.x), floorf(q2.y), floorf(q2.z));
+                const uint32_t seed0 = cell_hash_seed(f2);   // the neighbours' seeds differ from it by wave-uniform constants
+#pragma unroll 8
+                for (int cell = 0; cell < 8; ++cell) {
+                    const int dx = cell >> 2, dy = (cell >> 1) & 1, dz = cell & 1;
+                    const uint32_t seed = seed0 + static_cast<uint32_t>(dx * kHashX + dy * kHashY + dz * kHashZ);
+                    const f3 gm = mk3(f2.x + (dx ? 0.5f : -0.5f), f2.y + (dy ? 0.5f : -0.5f), f2.z + (dz ? 0.5f : -0.5f));
+                    const MinorCell mc = minor_cell(q2, seed, gm, off, scale, is_tiny);
+                    if (!is_tiny) {
+                        if (mc.pass && mc.c50 < 0.0f && mc.age <= min_age) {
+                            least_c50 = fminf(least_c50, mc.c50);
+                            min_age = mc.age;
+                        }
+                    } else if (mc.pass && mc.age <= min_age && mc.c50 < kTinyReach) {
+                        tiny = fmaxf(tiny, tiny_term(mc));
+                    }
+                }
+            }
+        }
+        noise_ring_rounds(cl, lds, lane, done, staged, true);
+        if (active) sum_fallout();
+    }
+    if (active && !overflow) {
         const float nf1 = lds[kFin + 2u * lane], nf2 = lds[kFin + 2u * lane + 1u];
-        out = near_total(s, big_fix, crater_small, tiny, fallout, nf1, nf2);
+        out = near_total(s, big_fix, small_total(least_c50), tiny, fallout, nf1, nf2);
         noise_calls = 2u * n_dep + 2u;
     }
     wave_lds_fence();
@@ -649,7 +727,7 @@ __device__ __forceinline__ CraterTableRegs no_crater_table() {
     return CraterTableRegs{make_float4(1e30f, 1e30f, 1e30f, 1.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f), 0.0f, 1.0f, 0xffffffffu};
 }
 
-__device__ __forceinline__ void wave_near(const float* crater_table, const unsigned long long* crater_masks, CraterTableRegs& cache, const CoopLane& cl, float* lds, uint32_t lane, uint32_t lane_threshold, bool wants,
+__device__ __forceinline__ void wave_near(const float* crater_table, const unsigned long long* crater_masks, const float4* minor_cells, CraterTableRegs& cache, const CoopLane& cl, float* lds, uint32_t lane, uint32_t lane_threshold, bool wants,
                                           f3 p, f3 off, float s, uint32_t crater_base, uint32_t crater_count, float& value, uint32_t& n_evals,
                                           uint32_t& n_noise) {
     unsigned long long todo = __ballot(wants);
@@ -679,7 +757,8 @@ __device__ __forceinline__ void wave_near(const float* crater_table, const unsig
         if (static_cast<uint32_t>(__popcll(need)) >= lane_threshold) {
             float v = 0.0f;
             uint32_t calls = 0;
-            const bool ok = lane_near(r0, r1, r2, cell_masks, cl, lds, mine, p, off, s, lane, v, calls);
+            const float4* minor = minor_cells ? minor_cells + static_cast<size_t>(packed >> 8) * kMinorCellsPerBall : nullptr;
+            const bool ok = lane_near(r0, r1, r2, cell_masks, minor, cl, lds, mine, p, off, s, lane, v, calls);
             if (mine && ok) {
                 value = v;
                 n_noise += calls;

@@ -110,6 +110,9 @@ struct SceneDev {
     // query can fall into, the mask of table entries within the 4^3 cells the reference visits from there; the ball's
     // ordinal sits above the low 8 bits of PrimRec::q[1]
     const unsigned long long* crater_masks;
+    // per crater ball, in the same order: the small and tiny craters' lattice cells about the ball (craterball.h:
+    // k_minor_cells), 16 bytes per cell; null: the evaluators compute the cells as they go
+    const void* minor_cells;
     // the raw noise transform (Linear row-major, then the translation), read by the SDF kinds that run noise() octave by octave
     const float* noise_raw;
     uint32_t plain_sdf;            // the scene holds SDF kinds evaluated one point per lane (RoughBoxObject)

@@ -86,6 +86,9 @@ void launch_generate(hipStream_t, const CameraRec&, const BatchParams&, const Pa
 void launch_extend(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t bounce, int stack_need, bool count = false);
 // big-crater candidates of a crater ball: 12 floats per cell of the n^3 lattice cube at `base` (x-major)
 void launch_crater_cells(hipStream_t, const float off[3], const int base[3], int n, float* out);
+// The small and tiny craters' cell tables of one crater ball (craterball.h: k_minor_cells) into `out`.
+void launch_minor_cells(hipStream_t, const float off[3], void* out);
+size_t minor_cells_bytes_per_ball();
 void launch_sdf_march(hipStream_t, const SceneDev&, const BatchParams&, const PathBuffers&, uint32_t round);
 // signed distance of SDF primitive `prim` at n points of its local frame (device arrays)
 void launch_sdf_eval(hipStream_t, const SceneDev&, uint32_t prim, uint32_t lane_threshold, const float* pos3, uint32_t n, float* out);

@@ -1630,7 +1630,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN 
         // (4) near-field evaluations for the crater-ball lanes that need one
         const bool wants = state == MARCH && result == 0 && !(PLAIN && plain);
         float d2 = 0.0f;
-        wave_near(sc.craters, sc.crater_masks, crater_regs, cl, lds, lane, bp.lane_threshold, wants, m.p, off, s, crater_base, crater_count, d2, c_near, c_noise);
+        wave_near(sc.craters, sc.crater_masks, static_cast<const float4*>(sc.minor_cells), crater_regs, cl, lds, lane, bp.lane_threshold, wants, m.p, off, s, crater_base, crater_count, d2, c_near, c_noise);
         if (wants) result = march_step(m, d2, ball_box, shortcuts);
         // (5) finished marches fold into the ray's best hit and move on to the next primitive
         late_now = false;
@@ -1740,7 +1740,7 @@ __global__ void __launch_bounds__(256) k_sdf_eval(SceneDev sc, uint32_t prim, ui
         } else if (valid) {
             v = plain_sdf(kind, prm, sc.noise_raw, p);
         }
-        if (kind == 3u) wave_near(sc.craters, sc.crater_masks, crater_regs, cl, lds, lane, lane_threshold, wants, p, prm, s, crater_base, crater_count, v, c_near, c_noise);
+        if (kind == 3u) wave_near(sc.craters, sc.crater_masks, static_cast<const float4*>(sc.minor_cells), crater_regs, cl, lds, lane, lane_threshold, wants, p, prm, s, crater_base, crater_count, v, c_near, c_noise);
         if (valid) out[i] = v;
     }
 }
@@ -2095,7 +2095,7 @@ __device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchPa
             pn = plain_normals(plain, off, sc.noise_raw, local_hit, e);
             if (plain == 6u) c_evals += 2;
         }
-        wave_near(sc.craters, sc.crater_masks, crater_regs, cl, lds, lane, bp.lane_threshold, wants, p, off, s, crater_base, crater_count, v, c_near, c_noise);
+        wave_near(sc.craters, sc.crater_masks, static_cast<const float4*>(sc.minor_cells), crater_regs, cl, lds, lane, bp.lane_threshold, wants, p, off, s, crater_base, crater_count, v, c_near, c_noise);
         const float v0 = dpp_f<0x00>(0.0f, v), v1 = dpp_f<0x55>(0.0f, v), v2 = dpp_f<0xAA>(0.0f, v), v3 = dpp_f<0xFF>(0.0f, v);   // quad broadcasts
         bool alive = false;
         if (valid && e == 0u) {
@@ -2410,6 +2410,10 @@ void launch_extend(hipStream_t st, const SceneDev& sc, const BatchParams& bp, co
 void launch_crater_cells(hipStream_t st, const float off[3], const int base[3], int n, float* out) {
     hipLaunchKernelGGL(k_crater_cells, dim3((n * n * n + 255) / 256), dim3(256), 0, st, off[0], off[1], off[2], base[0], base[1], base[2], n, reinterpret_cast<float4*>(out));
 }
+void launch_minor_cells(hipStream_t st, const float off[3], void* out) {
+    hipLaunchKernelGGL(k_minor_cells, dim3((kMinorCellsPerBall + 255u) / 256u), dim3(256), 0, st, off[0], off[1], off[2], static_cast<float4*>(out));
+}
+size_t minor_cells_bytes_per_ball() { return static_cast<size_t>(kMinorCellsPerBall) * sizeof(float4); }
 
 void launch_sdf_march(hipStream_t st, const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t bounce) {
     // persistent waves: enough blocks to fill the chip a few times over, every wave drains the queue
