@@ -254,6 +254,9 @@ __device__ __forceinline__ float near_total(float s, int big_fix, float crater_s
 // that passes the shell test, {+inf, 0, 0, hash bits} for one that does not (its distance from any query is then +inf,
 // which fails every later test the way `pass` did).  Made once per ball by k_minor_cells with the very functions the
 // evaluators use, so a value read from the table is the value computed on the spot, bit for bit.
+#ifndef MIPT_CELLS_IN_FLIGHT
+#define MIPT_CELLS_IN_FLIGHT 4
+#endif
 constexpr int kSmallCube = 24, kTinyCube = 124;
 constexpr uint32_t kSmallCells = kSmallCube * kSmallCube * kSmallCube, kTinyCells = kTinyCube * kTinyCube * kTinyCube;
 constexpr uint32_t kMinorCellsPerBall = kSmallCells + kTinyCells;   // float4s per ball: the small craters' cube, then the tiny ones'
@@ -653,14 +656,18 @@ __device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, const
             const f3 q_tiny = mk3(fmaf(u.x, 60.0f, off.x), fmaf(u.y, 60.0f, off.y), fmaf(u.z, 60.0f, off.z));
             const float4* at_small = minor + minor_cell_index(q_small, off, 11.0f, kSmallCube);
             const float4* at_tiny = minor + kSmallCells + minor_cell_index(q_tiny, off, 61.0f, kTinyCube);
-            float4 rec[8];
+            // kInFlight entries in flight at a time: each is replaced, once used, by the entry kInFlight places on
+            const auto small_at = [&](int cell) { return at_small[((cell >> 2) * kSmallCube + ((cell >> 1) & 1)) * kSmallCube + (cell & 1)]; };
+            const auto tiny_at = [&](int cell) { return at_tiny[((cell >> 2) * kTinyCube + ((cell >> 1) & 1)) * kTinyCube + (cell & 1)]; };
+            constexpr int kInFlight = MIPT_CELLS_IN_FLIGHT;
+            float4 rec[kInFlight];
 #pragma unroll
-            for (int cell = 0; cell < 8; ++cell) rec[cell] = at_small[((cell >> 2) * kSmallCube + ((cell >> 1) & 1)) * kSmallCube + (cell & 1)];
+            for (int cell = 0; cell < kInFlight; ++cell) rec[cell] = small_at(cell);
             sum_fallout();
 #pragma unroll
             for (int cell = 0; cell < 8; ++cell) {
-                const MinorCell mc = minor_cell_from(q_small, rec[cell], false);
-                rec[cell] = at_tiny[((cell >> 2) * kTinyCube + ((cell >> 1) & 1)) * kTinyCube + (cell & 1)];
+                const MinorCell mc = minor_cell_from(q_small, rec[cell % kInFlight], false);
+                rec[cell % kInFlight] = cell + kInFlight < 8 ? small_at(cell + kInFlight) : tiny_at(cell + kInFlight - 8);
                 if (mc.c50 < 0.0f && mc.age <= min_age) {
                     least_c50 = fminf(least_c50, mc.c50);
                     min_age = mc.age;
@@ -668,7 +675,8 @@ __device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, const
             }
 #pragma unroll
             for (int cell = 0; cell < 8; ++cell) {
-                const MinorCell mc = minor_cell_from(q_tiny, rec[cell], true);
+                const MinorCell mc = minor_cell_from(q_tiny, rec[cell % kInFlight], true);
+                if (cell + kInFlight < 8) rec[cell % kInFlight] = tiny_at(cell + kInFlight);
                 if (mc.age <= min_age && mc.c50 < kTinyReach) tiny = fmaxf(tiny, tiny_term(mc));
             }
         }

@@ -11,6 +11,7 @@
   * the demo scene's primary-hit map at 256 x 256 with the measured disagreement printed and bounded at twice what was
     measured when the bound was set.
 """
+import dataclasses
 import os
 
 import numpy as np
@@ -110,32 +111,47 @@ SDF_MAX_ERR = 1.1e-5
 SDF_P999_ERR = 2.1e-6
 
 
-def test_craterball_sdf_values_against_the_restatement(alg, oracle):
+@pytest.mark.parametrize("offset", [None, (-2.9999998, 5.0000005, 0.99999994), (-77.99999, 1234.000001, 0.9999999)],
+                         ids=["demo-offset", "offset-at-cell-edges", "far-offset"])
+def test_craterball_sdf_values_against_the_restatement(alg, oracle, offset):
+    """CraterBallObject::signedDistance (PathTracerDemo.cpp:361-466) through mipt_sdf_eval against the restatement, and the
+    device's ways of computing it against each other: one point per lane with the small / tiny craters' cells read from the
+    ball's tables, the same with the cells computed on the spot (MIPT_CELL_TABLE_BALLS=0), all lanes on one point (which
+    computes them too), and the default mix -- the same bits from all four.  The second offset puts the ball where a
+    query's lattice cells come closest to the first and last cell of the tables' cubes.  The third is far from the
+    origin: offset + 60 u then carries 1e-4 of rounding, the function itself answers to the last bit of u, and only the
+    agreement of the device's evaluators is held (1.1e-4 from the restatement was measured, the march's own threshold)."""
     z = np.load(FIXTURE, allow_pickle=False)
     noise = z["out_noise12"]
     flat = S.demo_scene(alg, noise)
+    if offset is not None:
+        params = flat.params.copy()
+        params[0, :3] = np.array(offset, np.float32)
+        flat = dataclasses.replace(flat, params=params)
     r = np.random.RandomState(77)
     n = 200_000
     # near field: |p| - 0.5 <= 0.1 runs the crater / noise body; a few far points check the early-out
     radius = np.concatenate([r.uniform(0.36, 0.6, n - 4096), r.uniform(0.6, 1.2, 4096)])
-    p = (_unit(r.normal(size=(n, 3))) * radius[:, None]).astype(np.float32)
+    directions = _unit(r.normal(size=(n, 3)))
+    directions[:6] = np.concatenate([np.eye(3), -np.eye(3)])   # the queries with the extreme lattice coordinates
+    p = (directions * radius[:, None]).astype(np.float32)
     want = oracle.sdf_craterball(flat.params[0, :3], noise, p)
     values = {}
-    for thr in ("1", "65", None):   # every point by the per-lane evaluator, by the cooperative one, and the default mix
-        if thr is None:
-            os.environ.pop("MIPT_LANE_THRESHOLD", None)
-        else:
-            os.environ["MIPT_LANE_THRESHOLD"] = thr
+    for key, env in (("lane", {"MIPT_LANE_THRESHOLD": "1"}), ("lane-no-tables", {"MIPT_LANE_THRESHOLD": "1", "MIPT_CELL_TABLE_BALLS": "0"}),
+                     ("coop", {"MIPT_LANE_THRESHOLD": "65"}), ("default", {})):
+        os.environ.update(env)
         try:
             c = api.Context()
         finally:
-            os.environ.pop("MIPT_LANE_THRESHOLD", None)
+            for k in env:
+                os.environ.pop(k, None)
         try:
-            values[thr] = c.sdf_eval(c.upload(flat), 0, p)
+            values[key] = c.sdf_eval(c.upload(flat), 0, p)
         finally:
             c.close()
-    assert np.array_equal(values["1"], values["65"]) and np.array_equal(values["1"], values[None]), "the two evaluators disagree"
-    got = values[None]
+    for key in ("lane-no-tables", "coop", "default"):
+        assert np.array_equal(values["lane"], values[key]), f"the evaluators disagree: lane / {key}"
+    got = values["default"]
     err = np.abs(got.astype(np.float64) - want.astype(np.float64))
     near = np.linalg.norm(p, axis=1) - 0.5 <= 0.1
     print(f"crater-ball SDF, {near.sum()} near-field points: max |err| = {err[near].max():.3e}, 99.9th percentile = "
