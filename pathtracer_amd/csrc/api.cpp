@@ -119,8 +119,8 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Per-slot arrays of the path arena, in the order ensure_slots lays them out: ray origin, ray direction,
 // attenuation, radiance (float4 each), hit key (u64), hit position (float4), two live-path queues, the SDF-march
-// queue and the SDF-shade queue (u32 each).  The memory budget below is priced from the same table.
-constexpr size_t kSlotArrayBytes[10] = {16, 16, 16, 16, 8, 16, 4, 4, 4, 4};
+// queue and the SDF-shade queue (u32 each), the marches' starting points (float4).  The memory budget below is priced from the same table.
+constexpr size_t kSlotArrayBytes[11] = {16, 16, 16, 16, 8, 16, 4, 4, 4, 4, 16};
 constexpr size_t slot_bytes() {
     size_t b = 0;
     for (size_t v : kSlotArrayBytes) b += v;
@@ -170,8 +170,8 @@ int ensure_slots(mipt_ctx* c, size_t slots, size_t words) {
         off += align_up(bytes, 256);
         return o;
     };
-    size_t o_arr[10];
-    for (int k = 0; k < 10; ++k) o_arr[k] = take(n * kSlotArrayBytes[k]);
+    size_t o_arr[11];
+    for (int k = 0; k < 11; ++k) o_arr[k] = take(n * kSlotArrayBytes[k]);
     const size_t o_ro = o_arr[0], o_rd = o_arr[1], o_att = o_arr[2], o_rad = o_arr[3], o_key = o_arr[4], o_pos = o_arr[5];
     const size_t o_q0 = o_arr[6], o_q1 = o_arr[7], o_qs = o_arr[8], o_qss = o_arr[9];
     const size_t o_cnt = take(sizeof(BounceCounters) * kCounterRows);
@@ -199,6 +199,7 @@ int ensure_slots(mipt_ctx* c, size_t slots, size_t words) {
     c->pb.queue[1] = reinterpret_cast<uint32_t*>(b + o_q1);
     c->pb.sdf_queue = reinterpret_cast<uint32_t*>(b + o_qs);
     c->pb.sdf_shade_queue = reinterpret_cast<uint32_t*>(b + o_qss);
+    c->pb.march_start = reinterpret_cast<float4*>(b + o_arr[10]);
     c->pb.counters = reinterpret_cast<BounceCounters*>(b + o_cnt);
     c->pb.totals = reinterpret_cast<Totals*>(b + o_tot);
     c->pb.live_bits = reinterpret_cast<unsigned long long*>(b + o_bits);

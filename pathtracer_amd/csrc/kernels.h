@@ -18,6 +18,9 @@ struct PathBuffers {
     float4* hit_pos;      // xyz world hit position as Object::hitRay returns it
     uint32_t* queue[2];   // live path slots, ping-pong per bounce
     uint32_t* sdf_queue;  // slots whose ray entered an SDF primitive's box
+    // per slot that is in sdf_queue, written by the kernel that put it there: where the ray's first march starts
+    // {entry point in the object's frame, index of the SDF box | 1 << 31 if a march starts there}
+    float4* march_start;
     uint32_t* sdf_shade_queue;   // slots whose closest hit is an SDF primitive
     uint32_t* host_queue;        // slots handed to the host (rays that reach a host object's box; hits on host objects); null without host objects
     BounceCounters* counters;    // kCounterRows entries, one per round of the batch

@@ -834,6 +834,36 @@ __device__ __forceinline__ bool reaches_host_box(const SceneDev& sc, f3 o, f3 in
     return any;
 }
 
+// Where a ray that goes to the SDF queue starts its first march (SDFObjectCRTP::hitLocalRay include/Object.hpp:135-143:
+// the ray in the object's frame, its entry into localBoundingBox unless it starts inside): {entry point, index of the
+// SDF box | 1 << 31 if a march starts there}.  The kernel that finds the ray's closest analytic hit computes it, with
+// the ray in registers and -- for camera rays -- all lanes of a wave at it, and leaves it in PathBuffers::march_start
+// for k_sdf_march, whose waves would otherwise run these few hundred instructions (three exact divisions for the box
+// test, six for the entry point) every round for the handful of lanes that have just fetched a ray.  The boxes are
+// tried in order as the march does; at a FractalObject the search stops unprepared, because its march, done where the
+// ray is taken up, may bring the ray's limit in.
+__device__ __forceinline__ f3 plain_box(uint32_t kind, f3 prm);   // demo_sdf.h
+__device__ __forceinline__ float4 sdf_first_march(const SceneDev& sc, f3 o, f3 d, f3 inv_d, float limit) {
+    uint32_t k = 0, prepared = 0;
+    f3 p0 = mk3(0, 0, 0);
+    for (; k < sc.n_sdf; ++k) {
+        const SdfBox bx = sc.sdf_boxes[k];
+        float tn;
+        if (!slab(o, inv_d, bx.lo, bx.hi, limit, tn)) continue;
+        const PrimRec* pr = sc.prims + bx.prim;
+        if (pr->kind == 4u) break;
+        const f3 lo = aff_pos(pr->inv, o);
+        const f3 ld = lin_mul(pr->inv, d);
+        const f3 box = pr->kind >= 5u ? plain_box(pr->kind, mk3(pr->p[0], pr->p[1], pr->p[2])) : mk3(1.0f, 1.0f, 1.0f);
+        p0 = lo;
+        if (inside_rect(lo, box) || hit_rect(lo, ld, box, p0)) {
+            prepared = 0x80000000u;
+            break;
+        }
+    }
+    return make_float4(p0.x, p0.y, p0.z, __uint_as_float(k | prepared));
+}
+
 // Adds a per-lane counter into a 64-bit total with one atomic per wave.
 __device__ __forceinline__ void wave_add_total(unsigned long long* total, uint32_t v) {
 #pragma unroll
@@ -1111,6 +1141,7 @@ __global__ void __launch_bounds__(256) k_generate_extend(CameraRec cam, SceneDev
             if ((threadIdx.x & 63u) == 0u) pb.live_bits[static_cast<size_t>(s_cur) * words_per_sample + (id >> 6)] = kept;
         }
         pending_push(live, keep, t.slot, &pb.counters[0].n_live, pb.queue[0]);
+        if (wants_sdf) pb.march_start[t.slot] = sdf_first_march(sc, t.o, t.d, t.inv_d, t.limit);
         pending_push(to_sdf, wants_sdf, t.slot, &pb.counters[0].n_sdf, pb.sdf_queue);
         n_sdf_rays += wants_sdf ? 1u : 0u;
     }
@@ -1219,6 +1250,7 @@ __global__ void __launch_bounds__(256) k_extend(SceneDev sc, BatchParams bp, Pat
             pb.hit_key[t.slot] = t.best;
             pb.hit_pos[t.slot] = st4(t.best_pos);
             wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, t.o, t.d, t.inv_d, t.limit, !(bp.flags & kFlagFullMarch));
+            if (wants_sdf) pb.march_start[t.slot] = sdf_first_march(sc, t.o, t.d, t.inv_d, t.limit);
             t.busy = false;
         }
         pending_push(to_sdf, wants_sdf, t.slot, &pb.counters[bounce].n_sdf, pb.sdf_queue);
@@ -1278,7 +1310,9 @@ __global__ void __launch_bounds__(256) k_extend_few(SceneDev sc, BatchParams bp,
                         }
                     }
                 }
-                wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, o, d, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), limit, !(bp.flags & kFlagFullMarch));
+                const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, o, d, inv_d, limit, !(bp.flags & kFlagFullMarch));
+                if (wants_sdf) pb.march_start[slot] = sdf_first_march(sc, o, d, inv_d, limit);
             }
             pb.hit_key[slot] = best;
             pb.hit_pos[slot] = st4(best_pos);
@@ -1326,6 +1360,7 @@ __global__ void __launch_bounds__(256) k_extend_pair(SceneDev sc, BatchParams bp
             pb.hit_key[t.slot] = t.best;
             if (t.best == kMissKey) pb.hit_pos[t.slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             wants_sdf = reaches_sdf_box(sc, box_lo, box_hi, t.o, t.d, t.inv_d, t.limit, !(bp.flags & kFlagFullMarch));
+            if (wants_sdf) pb.march_start[t.slot] = sdf_first_march(sc, t.o, t.d, t.inv_d, t.limit);
             pair_idle(t);
         }
         pending_push(to_sdf, wants_sdf, slot_was, &pb.counters[bounce].n_sdf, pb.sdf_queue);
@@ -1508,20 +1543,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN 
             if (have) {
                 const bool carried = i < n_in;
                 uint4 rec0 = make_uint4(0u, 0u, 0u, 0u);   // slot, primitive, best hit key
+                float4 start = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (carried) {
                     rec0 = *reinterpret_cast<const uint4*>(carry_in + i);
                     slot = rec0.x;
+                    k = rec0.y;
                 } else {
                     slot = pb.sdf_queue[i - n_in];
+                    start = pb.march_start[slot];
+                    k = __float_as_uint(start.w) & 0x7fffffffu;
                 }
                 best = carried ? ((static_cast<unsigned long long>(rec0.w) << 32) | rec0.z) : pb.hit_key[slot];
-                // A handed-on ray's slot holds kCarriedKey, so its key is always written back.  Its march is set up on its
-                // primitive as it was the first time (same ray, same best hit: the same box test and entry point) and
-                // then put where the last launch left it.
+                // A handed-on ray's slot holds kCarriedKey, so its key is always written back.  Its march goes on on the
+                // primitive it was on (the state follows from the record below).
                 improved = carried;
                 resumed = carried ? (i + 1u) | 0x80000000u : 0u;
-                k = rec0.y;
                 state = SETUP;
+                if (carried || (__float_as_uint(start.w) & 0x80000000u)) {
+                    // the march's start is known (k_march_setup): what is left of the set-up is the object's parameters
+                    const PrimRec* pr = sc.prims + sc.sdf_boxes[k].prim;
+                    off = mk3(pr->p[0], pr->p[1], pr->p[2]);
+                    crater_base = __float_as_uint(pr->q[0]);
+                    crater_count = __float_as_uint(pr->q[1]);
+                    if (PLAIN) plain = pr->kind >= 5u ? pr->kind : 0u;
+                    march_begin(m, mk3(start.x, start.y, start.z), lin_mul(pr->inv, ld3(pb.ray_d[slot])));
+                    state = MARCH;
+                }
             }
         }
         // (2) set up the march on the next SDF primitive whose box the ray reaches
