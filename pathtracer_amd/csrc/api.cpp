@@ -999,6 +999,8 @@ int mipt_scene_upload_host(mipt_ctx* c, const mipt_scene_desc* d, uint32_t flags
         for (const int32_t link : {nd.child0, nd.child1})
             if (link >= 0 ? static_cast<uint32_t>(link) >= n_nodes : static_cast<uint32_t>(~link) >= n) return MIPT_ERR_HIP;
     Bvh4Result bvh4 = collapse_bvh4(bvh.nodes.data(), bvh.nodes.size(), n);
+    // PathBuffers::march_start keeps the index of an SDF box in 20 bits
+    if (sdf.size() >= (size_t(1) << 20)) return MIPT_ERR_TOO_LARGE;
     // the deepest traversal stack the kernels carry; only a great many coincident boxes get there
     if (bvh4.stack_need > kMaxTraversalStack) return MIPT_ERR_TOO_LARGE;
     // the traversal addresses a node by a 32-bit byte offset (index * 128)

@@ -836,7 +836,7 @@ __device__ __forceinline__ bool reaches_host_box(const SceneDev& sc, f3 o, f3 in
 
 // Where a ray that goes to the SDF queue starts its first march (SDFObjectCRTP::hitLocalRay include/Object.hpp:135-143:
 // the ray in the object's frame, its entry into localBoundingBox unless it starts inside): {entry point, index of the
-// SDF box | 1 << 31 if a march starts there}.  The kernel that finds the ray's closest analytic hit computes it, with
+// SDF box (20 bits) | far-field steps already taken << 20 | 1 << 31 if a march starts there}.  The kernel that finds the ray's closest analytic hit computes it, with
 // the ray in registers and -- for camera rays -- all lanes of a wave at it, and leaves it in PathBuffers::march_start
 // for k_sdf_march, whose waves would otherwise run these few hundred instructions (three exact divisions for the box
 // test, six for the entry point) every round for the handful of lanes that have just fetched a ray.  The boxes are
@@ -844,7 +844,7 @@ __device__ __forceinline__ bool reaches_host_box(const SceneDev& sc, f3 o, f3 in
 // ray is taken up, may bring the ray's limit in.
 __device__ __forceinline__ f3 plain_box(uint32_t kind, f3 prm);   // demo_sdf.h
 __device__ __forceinline__ float4 sdf_first_march(const SceneDev& sc, f3 o, f3 d, f3 inv_d, float limit) {
-    uint32_t k = 0, prepared = 0;
+    uint32_t k = 0, prepared = 0, iter = 0;
     f3 p0 = mk3(0, 0, 0);
     for (; k < sc.n_sdf; ++k) {
         const SdfBox bx = sc.sdf_boxes[k];
@@ -858,10 +858,27 @@ __device__ __forceinline__ float4 sdf_first_march(const SceneDev& sc, f3 o, f3 d
         p0 = lo;
         if (inside_rect(lo, box) || hit_rect(lo, ld, box, p0)) {
             prepared = 0x80000000u;
+            if (pr->kind == 3u) {
+                // A crater ball's far-field steps (signedDistance = |p| - 0.5 where that exceeds 0.1,
+                // PathTracerDemo.cpp:362-366) are taken here as well, all but the last: the state handed over is the
+                // one whose next step is that last far-field step, which sets the march's step length anew -- so the
+                // point and the number of steps taken are all there is to hand over.
+                f3 p = p0;
+                while (iter < 255u) {
+                    const float s = norm(p) - 0.5f;
+                    if (!(static_cast<double>(s) > 0.1)) break;
+                    const f3 q = p + fabsf(s) * ld;
+                    if (!inside_rect(q, box)) break;
+                    p0 = p;
+                    p = q;
+                    ++iter;
+                }
+                if (iter) --iter;   // (p0 is the state before the last step taken)
+            }
             break;
         }
     }
-    return make_float4(p0.x, p0.y, p0.z, __uint_as_float(k | prepared));
+    return make_float4(p0.x, p0.y, p0.z, __uint_as_float(k | (iter << 20) | prepared));
 }
 
 // Adds a per-lane counter into a 64-bit total with one atomic per wave.
@@ -1443,10 +1460,12 @@ __device__ __forceinline__ bool same_bits(f3 a, f3 b) {
 //     back, the branch is taken again with a smaller d, for ever;
 //   * a state comes back bit for bit: the march is on a cycle none of whose states ended it (found by
 //     Brent's search: remember the state at step counts 1, 2, 4, ... and compare every later one with it).
+//     Far-field steps (`search` off) stay out of the search: a sequence that repeats still repeats without them,
+//     and so the search's state does not have to travel with a march whose far-field steps another kernel takes.
 // Where the SDF jumps across zero (crater rims, foam walls) the bisection cannot find a root, and rays
 // that start on the surface do this often: 2.8 % of them used to run all 256 iterations, 31 % of all
 // evaluations of those launches.  `shortcuts` off (MIPT_FULL_MARCH=1) runs every iteration, for the tests.
-__device__ __forceinline__ int march_step(March& m, float d2, f3 box, bool shortcuts) {
+__device__ __forceinline__ int march_step(March& m, float d2, f3 box, bool shortcuts, bool search = true) {
     if (m.first) {
         m.d = d2;
         m.sign = d2 > 0.0f;
@@ -1463,7 +1482,7 @@ __device__ __forceinline__ int march_step(March& m, float d2, f3 box, bool short
         m.p = m.p + fabsf(m.d) * m.dir;
         if (!inside_rect(m.p, box)) return 2;
     }
-    if (shortcuts) {
+    if (shortcuts && search) {
         if (same_bits(m.p, m.seen_p) && __float_as_uint(m.d) == __float_as_uint(m.seen_d)) return 2;
         if (++m.since == m.span) {
             m.seen_p = m.p;
@@ -1551,7 +1570,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN 
                 } else {
                     slot = pb.sdf_queue[i - n_in];
                     start = pb.march_start[slot];
-                    k = __float_as_uint(start.w) & 0x7fffffffu;
+                    k = __float_as_uint(start.w) & 0xfffffu;
                 }
                 best = carried ? ((static_cast<unsigned long long>(rec0.w) << 32) | rec0.z) : pb.hit_key[slot];
                 // A handed-on ray's slot holds kCarriedKey, so its key is always written back.  Its march goes on on the
@@ -1567,6 +1586,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN 
                     crater_count = __float_as_uint(pr->q[1]);
                     if (PLAIN) plain = pr->kind >= 5u ? pr->kind : 0u;
                     march_begin(m, mk3(start.x, start.y, start.z), lin_mul(pr->inv, ld3(pb.ray_d[slot])));
+                    // far-field steps the set-up took: they count as this kernel's, and the first step is behind the march
+                    m.iter = (__float_as_uint(start.w) >> 20) & 0xffu;
+                    m.first = m.iter == 0u;
+                    m.sign = true;
+                    c_far += m.iter;
                     state = MARCH;
                 }
             }
@@ -1670,7 +1694,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PLAIN 
                 s = norm(m.p) - 0.5f;
                 if (!(static_cast<double>(s) > 0.1)) break;   // `sdf_sphere > 0.1` compares against a double literal
                 ++c_far;
-                result = march_step(m, s, ball_box, shortcuts);
+                result = march_step(m, s, ball_box, shortcuts, false);
                 if (result) break;
             }
         }
