@@ -184,7 +184,10 @@ const char* mipt_strerror(int status);
 /* Scene::updateGeometry (src/Scene.cpp:80-87) + ObjectTree::Tree::Tree (src/ObjectTree.cpp:80-83):
  * packs primitives and materials into HBM and builds the linear BVH (a scalable builder replaces
  * makeTree, src/ObjectTree.cpp:90-184; any topology returns the same closest hit because the
- * reference's tree never culls). */
+ * reference's tree never culls).  Device memory: 128 bytes per primitive, 64 per tree node and material, and per
+ * MIPT_CRATERBALL 30.7 MB of tables (the hashed lattice cells of its small and tiny craters, which depend on the
+ * ball's offset alone; scenes with more than 64 balls -- MIPT_CELL_TABLE_BALLS -- go without and compute the cells
+ * per evaluation, same values).  MIPT_ERR_TOO_LARGE from 2^20 SDF primitives. */
 int  mipt_scene_upload(mipt_ctx*, const mipt_scene_desc*, mipt_scene** out);
 /* The same with build options.  MIPT_UPLOAD_DEVICE_BVH builds the tree on the GPU (Morton order + radix tree, a few
  * launches) instead of on the host (binned surface-area heuristic): for scenes whose objects move every frame, where
