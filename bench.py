@@ -333,19 +333,23 @@ def main():
         achieved = bytes_alg / (trav_ms * 1e-3) / 1e9
         # HBM-side traffic of the same kernels from the committed counter pass of this command (reads only; a wide read is tallied at half its bytes)
         traffic = traffic_source = None
+        traffic_launches = 0
         prof = {("random100k", 1920, 1080, 256): "random100k_256spp", ("mixed20k", 3840, 2160, 64): "mixed20k_4k_64spp",
                 ("random1m", 3840, 2160, 32): "random1m_4k_32spp"}.get((a.scene, W, H, a.spp))
         if prof and world == 1:
             path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_fetch_{prof}.csv")
             # (the first rows are the plain, not the counting, builds; camera rays come from the fused kernel or, written out by k_generate, through k_extend_pair)
-            ext, gen = pmc_rows(path, "k_extend"), pmc_rows(path, "k_generate_extend<") or pmc_rows(path, "k_generate")
-            if ext and gen:
-                traffic = 2.0 * (ext["FETCH_SIZE"] + gen["FETCH_SIZE"]) * 1024.0 / max(1.0, ext["dispatches"] + gen["dispatches"])
+            # (k_generate, which only writes rays out, reads nothing and is left out of the average)
+            ext, gen = pmc_rows(path, "k_extend"), pmc_rows(path, "k_generate_extend<")
+            if ext:
+                fetch_kb = ext["FETCH_SIZE"] + (gen["FETCH_SIZE"] if gen else 0.0)
+                traffic = 2.0 * fetch_kb * 1024.0 / max(1.0, ext["dispatches"] + (gen["dispatches"] if gen else 0.0))
+                traffic_launches = max(1, (launches.get("extend", 0) + (launches.get("generate", 0) if gen else 0)) // a.steps)
                 traffic_source = f"profiles/{PROFILE_ROUND}_pmc_fetch_{prof}.csv: 2 x FETCH_SIZE KB per launch (reads that go past L2; wide reads corrected x2)"
         # The tree fits the caches (3.2 MB of nodes + 12.8 MB of records at 100k objects), so the algorithmic bytes are
         # served by the L2s, not by HBM: the roofline they are priced against is the chip's L2 gather rate, and what HBM
         # itself moved is `traffic`.
-        hbm_frac = traffic * n_launch / (trav_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if traffic else None
+        hbm_frac = traffic * traffic_launches / (trav_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if traffic else None
         tests_per_ray = cst["prim_tests"] / max(1, cst["rays"])
         out["roofline"] = {"kernel": "k_generate_extend + k_extend_pair (closest hit)", "bound": "l2",
                            "bound_detail": "gather of 64-B four-child nodes and 128-B primitive records out of L1 / L2 / Infinity Cache; measured limiter: "

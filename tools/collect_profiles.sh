@@ -23,7 +23,7 @@ pmc() {     # <name> <counters...> -- <bench args...>
   shift
   rm -rf /tmp/pmc_$name
   timeout -s KILL 400 rocprofv3 --pmc "${ctrs[@]}" -d /tmp/pmc_$name -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > /tmp/pmc_$name.log 2>&1
-  python3 $R/tools/pmc_sum.py /tmp/pmc_$name $OUT/${T}_pmc_$name.csv "rocprofv3 --pmc ${ctrs[*]} -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $*; sums over all dispatches of each kernel in one frame"
+  python3 $R/tools/pmc_sum.py /tmp/pmc_$name $OUT/${T}_pmc_$name.csv "rocprofv3 --pmc ${ctrs[*]} -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $*; sums over all dispatches of each kernel in the run (column dispatches): one frame, and on the analytic scenes a second one with the counting build (k_extend_pair<.., true, ..>); a frame of more paths than the arena holds is several batches, each with its own launches"
   echo "pmc $name done"
 }
 
@@ -45,6 +45,7 @@ for sc in random100k mixed20k random1m; do
   pmc sq_$N SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU -- $A
   pmc cache_$N TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum -- $A
   pmc fetch_$N FETCH_SIZE -- $A
+  pmc write_$N WRITE_SIZE -- $A
   # the vector-memory pipeline in front of the caches (address unit and L1 of every CU), what the traversal is bound by
   pmc ta_$N TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_GATE_EN1_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum GRBM_GUI_ACTIVE -- $A
   bench_reads $OUT/${T}_pmc_fetch_$N.csv
