@@ -59,6 +59,7 @@ struct mipt_ctx {
     // round's launch (BatchParams::carry_max_lag, carry_after)
     uint32_t carry_lag = 4, carry_after = 32;
     size_t minor_table_balls = 64;  // MIPT_CELL_TABLE_BALLS: scenes with up to this many crater balls get the small / tiny crater cell tables (0: none)
+    uint32_t sort_marches = 2;      // MIPT_SORT_MARCHES: rounds 1 .. this sort their SDF queue by the rays' first query cell (0: never)
     bool no_few = false;            // MIPT_NO_FEW=1 (test aid): the closest-hit kernel for scenes of a handful of primitives is not used
     int split_primary = -1;         // MIPT_SPLIT_PRIMARY: 1 = camera rays are written out and traced by the later bounces' kernel, 0 = by the fused kernel, unset = by scene
     uint32_t carry_cap = 0;         // records in each of the two hand-over buffers of the arena
@@ -640,6 +641,7 @@ int render_into(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam, const
         bp.flags = (st->flags & static_cast<uint32_t>(MIPT_FLAG_NO_JITTER)) | (c->full_march ? kFlagFullMarch : 0u);
         bp.lane_threshold = c->lane_threshold;
     bp.no_few = c->no_few ? 1u : 0u;
+    bp.sort_marches = sc->host_prims.empty() ? c->sort_marches : 0u;   // (the host pass works on the queues between the stages)
         // marches are handed on only where nothing synchronises with the host inside a batch
         bp.carry_max_lag = (sc->n_sdf && sc->host_prims.empty()) ? std::min<uint32_t>(c->carry_lag, kCounterRows - 1 - st->bounces) : 0u;
         bp.carry_after = c->carry_after;
@@ -771,6 +773,7 @@ int mipt_init(int device, void* stream, mipt_ctx** out) {
     if (const char* e = std::getenv("MIPT_FULL_MARCH")) c->full_march = std::atoi(e) != 0;
     if (const char* e = std::getenv("MIPT_CARRY_LAG")) c->carry_lag = static_cast<uint32_t>(std::min(long(kMaxCarryLag), std::max(0L, std::atol(e))));
     if (const char* e = std::getenv("MIPT_NO_FEW")) c->no_few = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MIPT_SORT_MARCHES")) c->sort_marches = static_cast<uint32_t>(std::min(64, std::max(0, std::atoi(e))));
     if (const char* e = std::getenv("MIPT_CELL_TABLE_BALLS")) c->minor_table_balls = static_cast<size_t>(std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("MIPT_SPLIT_PRIMARY")) c->split_primary = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("MIPT_CARRY_AFTER")) c->carry_after = static_cast<uint32_t>(std::min(100000L, std::max(0L, std::atol(e))));
@@ -1392,6 +1395,7 @@ int mipt_primary_hits(mipt_ctx* c, const mipt_scene* sc, const mipt_camera* cam,
     bp.flags = MIPT_FLAG_NO_JITTER | (c->full_march ? kFlagFullMarch : 0u);
     bp.lane_threshold = c->lane_threshold;
     bp.no_few = c->no_few ? 1u : 0u;
+    bp.sort_marches = sc->host_prims.empty() ? c->sort_marches : 0u;   // (the host pass works on the queues between the stages)
     bp.trav_quorum = c->trav_quorum;
     bp.trav_quorum_primary = c->trav_quorum_primary;
     bp.trav_keep = c->trav_keep;
@@ -1451,6 +1455,7 @@ int mipt_trace_rays(mipt_ctx* c, const mipt_scene* sc, uint32_t n, const float* 
     bp.height = 1;
     bp.lane_threshold = c->lane_threshold;
     bp.no_few = c->no_few ? 1u : 0u;
+    bp.sort_marches = sc->host_prims.empty() ? c->sort_marches : 0u;   // (the host pass works on the queues between the stages)
     bp.trav_quorum = c->trav_quorum;
     bp.trav_quorum_primary = c->trav_quorum_primary;
     bp.trav_keep = c->trav_keep;

@@ -127,6 +127,8 @@ struct SceneDev {
 #endif
 constexpr uint32_t kMarchCursors = MIPT_MARCH_CURSORS;
 
+constexpr uint32_t kSortKeys = 1024;   // sort keys of the SDF queue: the 9^3 query cells of a crater ball and a few for everything else
+
 // Per-bounce queue counters of one sample batch, zeroed once per batch.
 struct BounceCounters {
     uint32_t n_live;        // entries in the path queue feeding this bounce (bounce > 0)
@@ -142,6 +144,10 @@ struct BounceCounters {
     // work-fetch cursors of the SDF march, each on a cache line of its own: atomics on one line are served one at a time
     uint32_t sdf_heads[kMarchCursors][32];
     uint32_t extend_heads[8][32];   // work-fetch cursors of extend, one per XCD, likewise
+    // the SDF queue's rays sorted by the lattice cell of their first query (k_sort_*): rays per key, and where each
+    // key's run begins / has been filled to in the sorted queue
+    uint32_t sort_hist[kSortKeys];
+    uint32_t sort_cursor[kSortKeys];
 };
 
 // An SDF march that its launch handed on to the next round's launch instead of finishing it (k_sdf_march): everything

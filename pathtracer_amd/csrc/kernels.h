@@ -65,6 +65,7 @@ struct BatchParams {
     // wave has gone carry_after more rounds, if their path has fallen behind fewer than carry_max_lag times (0: every
     // launch finishes its marches) and the buffer of carry_cap records has room.
     uint32_t carry_max_lag, carry_after, carry_cap;
+    uint32_t sort_marches;       // rounds 1 .. sort_marches sort their SDF queue by the rays' first query cell before the march (0: never)
     uint32_t no_few;             // test aid: scenes of a handful of primitives walk their tree like any other (1) instead of testing every primitive per ray
     uint64_t seed;
 };

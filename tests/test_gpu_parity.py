@@ -380,6 +380,52 @@ def test_sdf_value_is_independent_of_evaluator():
     assert frames[0][1]["sdf_near_evals"] > 10000
 
 
+def test_frame_does_not_depend_on_how_the_march_is_scheduled(golden):
+    """Which launch finishes a march (MIPT_CARRY_LAG), in which order a launch takes its rays (MIPT_SORT_MARCHES), whether
+    the small / tiny craters' cells are read from a ball's tables or computed (MIPT_CELL_TABLE_BALLS) and which kernel
+    finds the analytic hits of a scene of a handful of primitives (MIPT_NO_FEW) are matters of speed: the frame and every
+    work counter must be the same.  Two crater balls (two crater tables, two pairs of cell tables), a fractal in front of
+    one of them (a first march that cannot be set up ahead), a rough box (the lane-evaluated kind), a mirror and a light."""
+    import os
+    alg = api.HostAlgebra()
+    b = S.SceneBuilder(alg, golden["noise12"])
+    grey = S.material(diffuse=1.0, specular=0.0, albedo=(0.6, 0.6, 0.6))
+    b.craterball((-8.0, 15.0, -6.5), grey, S.translation(-0.7, 0.4, 0.0))
+    b.craterball((3.25, -1.5, 7.75), grey, alg.affine_mul(S.translation(0.9, -0.2, 0.6), S.scale(0.8)))
+    b.fractal(grey, alg.affine_mul(S.translation(-0.6, 0.3, -1.6), S.scale(0.35)))
+    b.roughbox((0.3, 0.25, 0.3), grey, S.translation(0.2, 1.1, -0.3))
+    b.sphere(0.4, S.material(diffuse=0.05, specular=0.95, sharpness=0.95), S.translation(0.1, -0.9, -0.4))
+    b.box((30.0, 0.1, 30.0), S.material(diffuse=1.0, specular=0.0, emitted=(2.0, 2.0, 2.0)), S.translation(0.0, -12.0, 0.0))
+    flat = b.build()
+    cam = S.camera(S.translation(0.0, 0.0, -9.0), aspect=1.0, fov=22.0, focal=9.0, blur=0.0)
+    switches = ("MIPT_CARRY_LAG", "MIPT_SORT_MARCHES", "MIPT_CELL_TABLE_BALLS", "MIPT_NO_FEW")
+    old = {k: os.environ.get(k) for k in switches}
+    frames = []
+    try:
+        for env in ({}, {"MIPT_CARRY_LAG": "0"}, {"MIPT_SORT_MARCHES": "0"}, {"MIPT_SORT_MARCHES": "8"}, {"MIPT_CELL_TABLE_BALLS": "0"},
+                    {"MIPT_CELL_TABLE_BALLS": "1"}, {"MIPT_NO_FEW": "1"}, {"MIPT_CARRY_LAG": "8", "MIPT_CARRY_AFTER": "2"}):
+            for k in switches + ("MIPT_CARRY_AFTER",):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            c = api.Context()
+            img, st = c.render(c.upload(flat), cam, 160, 160, 6, 12, seed=5)
+            frames.append((env, img, st))
+            c.close()
+    finally:
+        for k in switches + ("MIPT_CARRY_AFTER",):
+            os.environ.pop(k, None)
+        for k, v in old.items():
+            if v is not None:
+                os.environ[k] = v
+    _, img0, st0 = frames[0]
+    assert st0["sdf_near_evals"] > 100000 and st0["sdf_shades"] > 10000 and img0.max() > 0
+    assert frames[-1][2]["marches_carried"] > 0 and frames[1][2]["marches_carried"] == 0
+    for env, img, st in frames[1:]:
+        assert np.array_equal(img, img0), env
+        for key in ("rays", "sdf_rays", "sdf_shades", "sdf_near_evals", "sdf_far_evals", "sdf_noise_calls", "shade_noise_calls"):
+            assert st[key] == st0[key], (env, key)
+
+
 def test_marches_that_cannot_end_are_cut_short_without_changing_the_frame(golden):
     """A march whose state (p, d) stops changing, or comes back bit for bit, can only run out its 256 iterations
     and miss (include/Object.hpp:135-167), and a ray that stays farther than 0.6 from a crater ball's centre only

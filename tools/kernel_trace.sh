@@ -12,7 +12,7 @@ rows = list(csv.DictReader(open(path)))
 name = [k for k in rows[0] if k.lower() == "kernel_name"][0]
 s = [k for k in rows[0] if k.lower().startswith("start")][0]
 e = [k for k in rows[0] if k.lower().startswith("end")][0]
-for kern in ("k_sdf_march", "k_shade_sdf", "k_extend", "k_shade(", "k_generate"):
+for kern in ("k_sdf_march", "k_sort_keys", "k_sort_scan", "k_sort_scatter", "k_shade_sdf", "k_extend", "k_shade(", "k_generate"):
     d = [(int(r[s]), (int(r[e]) - int(r[s])) / 1e6) for r in rows if kern in r[name]]
     d.sort()
     per_frame = len(d) // 3   # three frames were traced (1 warm-up + 2)

@@ -14,7 +14,7 @@ from pathtracer_amd import api, scene as S   # noqa: E402
 
 W, H, BOUNCES = 1920, 1080, 8
 SAME = ("paths", "rays", "sdf_rays", "sdf_shades", "sdf_far_evals", "sdf_near_evals", "sdf_noise_calls", "shade_evals")
-SWITCHES = ("MIPT_CARRY_LAG", "MIPT_CARRY_AFTER", "MIPT_LANE_THRESHOLD", "MIPT_NO_FEW", "MIPT_CELL_TABLE_BALLS", "MIPT_FULL_MARCH")
+SWITCHES = ("MIPT_CARRY_LAG", "MIPT_CARRY_AFTER", "MIPT_LANE_THRESHOLD", "MIPT_NO_FEW", "MIPT_CELL_TABLE_BALLS", "MIPT_FULL_MARCH", "MIPT_SORT_MARCHES")
 
 
 def run(env, spp, frames=4):
