@@ -2196,7 +2196,10 @@ __global__ void __launch_bounds__(256) k_sdf_material(SceneDev sc, uint32_t prim
 // SDF hits: the normal is a forward difference of four SDF evaluations (signedDistanceNormal,
 // include/Object.hpp:118-132): at the hit and at +delta along x, y, z.  The four lanes of a quad take
 // the four points of one hit, so a wave shades 16 hits per round; the quad's first lane then deflects
-// the path.  Hits are dealt to waves round-robin so that a short queue spreads over all waves.
+// the path.  A wave takes sixteen CONSECUTIVE hits of the queue per round: neighbours in the queue are neighbours on
+// the object (camera rays' hits come in screen order), so the wave's sixteen crater lists are nearly one list and the
+// evaluator's loop, which runs for the longest of them, wastes little (dealt round-robin, a wave's hits were 3,000
+// entries apart: 21.7 ms per frame instead of 18.7).
 template <bool PLAIN>
 __device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t round, uint32_t max_bounces) {
     if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
@@ -2218,7 +2221,7 @@ __device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchPa
     const uint32_t e = lane & 3u;   // which of the four points
     const float delta = 1e-3f;
     for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t i = r * per_round + wave + (lane >> 2) * n_waves;
+        const uint32_t i = r * per_round + wave * 16u + (lane >> 2);
         const bool valid = i < n;
         uint32_t slot = 0, crater_base = 0, crater_count = 0;
         PrimRegs pr;
