@@ -2301,11 +2301,119 @@ __device__ __forceinline__ void shade_sdf_body(const SceneDev& sc, const BatchPa
     }
 }
 
+// The same for scenes whose SDF objects are crater balls and fractals only, 64 hits per wave and round: every lane
+// loads one hit and, at the end, deflects its path; in between, four passes of evaluations, in each of which the
+// quads work on the points of sixteen of the hits (a quad asks the lane that holds its hit for the point, the
+// lane collects the four values from its quad).  Loading and deflecting thus run with all lanes instead of one lane
+// of each quad.
+__device__ __forceinline__ void shade_sdf_body64(const SceneDev& sc, const BatchParams& bp, const PathBuffers& pb, uint32_t round, uint32_t max_bounces) {
+    if (*pb.cancel_latch) return;   // the frame was cancelled (as of the last latch)
+    const uint32_t n = pb.counters[round].n_sdf_shade;
+    uint32_t* next_queue = pb.queue[(round + 1) & 1];
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t per_round = n_waves * 64u;
+    const uint32_t rounds = (n + per_round - 1) / per_round;
+    uint32_t c_evals = 0, c_near = 0, c_noise = 0;
+    __shared__ __attribute__((aligned(16))) float s_near[4 * kNearLdsFloats];
+    constexpr uint32_t kCap = 128;   // small: three blocks of this kernel must fit the CU's LDS
+    __shared__ uint32_t s_pend[4 * kCap];
+    PendingQueue survivors{s_pend + (threadIdx.x >> 6) * kCap, kCap, 0u};
+    const uint32_t lane = __lane_id();
+    float* lds = s_near + (threadIdx.x >> 6) * kNearLdsFloats;
+    const CoopLane cl = make_coop_lane(sc.noise_oct, lane);
+    CraterTableRegs crater_regs = no_crater_table();
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t e = lane & 3u;   // which of a hit's four points this lane evaluates
+    const float delta = 1e-3f;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        // ---- this lane's hit ----
+        const uint32_t i = r * per_round + wave * 64u + lane;
+        const bool valid = i < n;
+        // (only what the evaluations need stays in registers across them; the rest of the hit is read again afterwards)
+        uint32_t slot = 0, crater_base = 0, crater_count = 0;
+        f3 off = mk3(0, 0, 0), local_hit = mk3(0, 0, 0);
+        bool fractal = false;
+        if (valid) {
+            slot = pb.sdf_shade_queue[i];
+            const PrimRec* rec = sc.prims + static_cast<uint32_t>(pb.hit_key[slot] & 0xffffffffu);
+            local_hit = aff_pos(rec->inv, ld3(pb.hit_pos[slot]));
+            fractal = rec->kind == 4u;
+            if (!fractal) {
+                off = mk3(rec->p[0], rec->p[1], rec->p[2]);
+                crater_base = __float_as_uint(rec->q[0]);
+                crater_count = __float_as_uint(rec->q[1]);
+            }
+        }
+        // ---- the four values of every crater-ball hit, sixteen hits a pass ----
+        const bool needs = valid && !fractal;
+        const unsigned long long need_mask = __ballot(needs);
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+#pragma unroll 1
+        for (uint32_t pass = 0; pass < 4u; ++pass) {
+            if (((need_mask >> (16u * pass)) & 0xffffull) == 0ull) continue;
+            const int src = 4 * static_cast<int>(16u * pass + (lane >> 2));   // (byte address of) the lane that holds this quad's hit
+            const bool ok = __builtin_amdgcn_ds_bpermute(src, needs ? 1 : 0) != 0;
+            const f3 base = mk3(fetch_lane(local_hit.x, src), fetch_lane(local_hit.y, src), fetch_lane(local_hit.z, src));
+            const f3 off_q = mk3(fetch_lane(off.x, src), fetch_lane(off.y, src), fetch_lane(off.z, src));
+            const uint32_t cb = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src, static_cast<int>(crater_base)));
+            const uint32_t cc = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src, static_cast<int>(crater_count)));
+            const f3 p = mk3(base.x + (e == 1u ? delta : 0.0f), base.y + (e == 2u ? delta : 0.0f), base.z + (e == 3u ? delta : 0.0f));
+            const float s = norm(p) - 0.5f;
+            if (ok) ++c_evals;
+            // the far field returns the sphere distance itself (`sdf_sphere > 0.1` compares against a double literal)
+            const bool wants = ok && !(static_cast<double>(s) > 0.1);
+            float v = s;
+            wave_near(sc.craters, sc.crater_masks, static_cast<const float4*>(sc.minor_cells), crater_regs, cl, lds, lane, bp.lane_threshold, wants, p, off_q, s, cb, cc, v, c_near, c_noise);
+            // lane 16 pass + h collects the values of quad h
+            const int quad = 16 * static_cast<int>(lane & 15u);
+            const float q0 = fetch_lane(v, quad), q1 = fetch_lane(v, quad + 4), q2 = fetch_lane(v, quad + 8), q3 = fetch_lane(v, quad + 12);
+            if ((lane >> 4) == pass) {
+                v0 = q0;
+                v1 = q1;
+                v2 = q2;
+                v3 = q3;
+            }
+        }
+        // ---- deflect ----
+        bool alive = false;
+        if (valid) {
+            f3 nrm;
+            if (fractal) {
+                nrm = fractal_normal(local_hit);
+            } else {
+                const f3 g = mk3(v1 - v0, v2 - v0, v3 - v0) * (1.0f / delta);
+                nrm = unit(g);
+            }
+            PrimRegs pr;
+            load_prim(sc.prims, static_cast<uint32_t>(pb.hit_key[slot] & 0xffffffffu), pr);
+            const f3 wp = ld3(pb.hit_pos[slot]);
+            const float4 dv = pb.ray_d[slot];
+            const uint32_t lag = __float_as_uint(dv.w);
+            const f3 ld = lin_mul(pr.inv, ld3(dv));
+            const uint32_t s_local = slot / bp.n_pix;
+            uint32_t px, py;
+            pixel_of(bp, slot - s_local * bp.n_pix, px, py);
+            const uint32_t bounce = round - lag;
+            Rng rng(bp.seed, py * bp.width + px, bp.first_sample + s_local, 1u + bounce);
+            const Bounce b = deflect(sc.materials[pr.material], ld, nrm, rng);
+            alive = apply_bounce(pb, slot, pr, wp, b, bounce, max_bounces, lag);
+        }
+        pending_push(survivors, alive, slot, &pb.counters[round + 1].n_live, next_queue);
+    }
+    __shared__ uint32_t s_meet[8];
+    pending_flush_block(survivors, &pb.counters[round + 1].n_live, next_queue, s_meet);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.totals->sdf_shades, static_cast<unsigned long long>(n));
+    if (rounds) {
+        wave_add_total(&pb.totals->shade_near_evals, c_evals);
+        wave_add_total(&pb.totals->shade_noise_calls, c_noise);
+    }
+}
+
 // Three waves per SIMD for the crater-ball instantiation (the register allocator would otherwise take one
 // register too many for that); the instantiation with the lane-evaluated kinds needs more and runs two.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_shade_sdf(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t round,
                                                                                            uint32_t max_bounces) {
-    shade_sdf_body<false>(sc, bp, pb, round, max_bounces);
+    shade_sdf_body64(sc, bp, pb, round, max_bounces);
 }
 __global__ void __launch_bounds__(256) k_shade_sdf_plain(SceneDev sc, BatchParams bp, PathBuffers pb, uint32_t round, uint32_t max_bounces) {
     shade_sdf_body<true>(sc, bp, pb, round, max_bounces);
