@@ -600,7 +600,7 @@ __device__ __forceinline__ bool lane_near(float4 t0, float4 t1, float4 t2, const
         const float4 r1 = make_float4(fetch_lane(t1.x, from), fetch_lane(t1.y, from), fetch_lane(t1.z, from), fetch_lane(t1.w, from));
         const float4 r2 = make_float4(fetch_lane(t2.x, from), fetch_lane(t2.y, from), 0.0f, 0.0f);
         bool dep = false;
-        BigCrater b = {};
+        BigCrater b;   // (read only where `dep` is set, which implies `in`: left uninitialised so that no lane zeroes it every pass)
         if (in) {
             b = big_crater(query, r0, r1, r2);
             big_fix += big_crater_fix(b);
